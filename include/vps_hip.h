@@ -1,0 +1,199 @@
+/* vps_hip.h -- C ABI of libvps_hip.so: the MI355X (gfx950) hot path
+ *   particles -> grid (NGP deposit | exact-NN resample) -> 3-D R2C FFT -> |f(k)|^2
+ *   -> spherical-shell binning
+ * that replaces the CPU path of YujieH3/large-velocity-power-spectrum behind the
+ * reference's own Python function surface.
+ *
+ * The reference has NO FFI of its own for this path (it is pure numpy calling
+ * pyFFTW / pyann / Annoy): every entry point below cites the
+ * reference Python function (file:line under /root/reference) whose arithmetic it
+ * replaces.  INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every function returns 0 on success or a
+ *     negative vps_status; nothing throws.  vps_last_error() gives the message.
+ *   - "dev" pointers are device (HBM) addresses owned by the CALLER (e.g.
+ *     torch.Tensor.data_ptr() or vps_malloc); "host" pointers are ordinary memory.
+ *   - All work is enqueued on the context's stream (vps_set_stream; default: the
+ *     null stream); only vps_sync, vps_timing_get, vps_memcpy_d2h block.
+ *   - Grids are float32, C order.  A multi-channel grid is channel-major (SoA):
+ *     grid[c][x][y][z].  Slab decomposition is along x: a rank owns
+ *     x in [x0, x0+nx).  N is the global cells-per-axis.
+ *   - Calls on one context are not re-entrant.
+ */
+#ifndef VPS_HIP_H
+#define VPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vps_ctx vps_ctx;
+
+enum vps_status {
+  VPS_OK = 0,
+  VPS_ERR_ARG = -1,        /* bad argument (message says which)                 */
+  VPS_ERR_HIP = -2,        /* a HIP runtime call failed                          */
+  VPS_ERR_UNSUPPORTED = -3,/* e.g. N not a supported FFT length                  */
+  VPS_ERR_NOMEM = -4
+};
+
+/* quantities of BoxField.spctrm (interp.py:573-583) */
+enum vps_quantity { VPS_VELOCITY = 0, VPS_MOMENTUM = 1, VPS_ENERGY = 2,
+                    VPS_VM = 3 /* BoxField form: v in channels 0..2, mass in channel 3 */ };
+/* flags for vps_field_algebra */
+#define VPS_FLAG_REFERENCE_MOMENTUM_BUG 1 /* py=pz=vx*mass as interp.py:523-525 */
+#define VPS_FLAG_INPUT_IS_VM 2             /* channels already hold vx,vy,vz,mass (a BoxField) */
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int vps_create(vps_ctx** out, int device_id);
+int vps_destroy(vps_ctx* ctx);
+const char* vps_last_error(const vps_ctx* ctx);   /* ctx may be NULL: global slot */
+int vps_set_stream(vps_ctx* ctx, void* hip_stream);
+int vps_sync(vps_ctx* ctx);
+int vps_version(void);                            /* ABI version, currently 1       */
+/* device facts for the host side: out[0]=CUs, out[1]=LDS bytes/CU, out[2]=wave size,
+ * out[3]=HBM bytes total (MiB) */
+int vps_device_info(vps_ctx* ctx, int64_t out[4]);
+
+/* ---- memory helpers (so the library is usable without torch) ------------ */
+int vps_malloc(vps_ctx* ctx, void** dev, size_t bytes);
+int vps_free(vps_ctx* ctx, void* dev);
+int vps_memset(vps_ctx* ctx, void* dev, int value, size_t bytes);
+int vps_memcpy_h2d(vps_ctx* ctx, void* dev, const void* host, size_t bytes);
+int vps_memcpy_d2h(vps_ctx* ctx, void* host, const void* dev, size_t bytes); /* blocks */
+
+/* ---- per-kernel timing (HIP events on the context's stream) -------------- */
+/* When enabled every kernel launched by the library is bracketed by events.
+ * vps_timing_get synchronises and returns, for kernel family `kind`, the launch
+ * count and the summed duration in milliseconds since vps_timing_reset. */
+enum vps_kernel_kind {
+  VPS_K_DEPOSIT = 0, VPS_K_ALGEBRA = 1, VPS_K_FFT_Z = 2, VPS_K_FFT_Y = 3,
+  VPS_K_FFT_X = 4, VPS_K_NN_BUILD = 5, VPS_K_NN_QUERY = 6, VPS_K_MISC = 7,
+  VPS_K_COUNT = 8
+};
+int vps_timing_enable(vps_ctx* ctx, int on);
+int vps_timing_reset(vps_ctx* ctx);
+int vps_timing_get(vps_ctx* ctx, int kind, int64_t* launches, double* total_ms);
+
+/* ---- stage A1: nearest-grid-point deposition ---------------------------- */
+/* Replaces deposit_to_grid (vpower/interp.py:996-1015).
+ * Cell index per axis = int((pos // Lcell) % N) evaluated with numpy's
+ * floor_divide/remainder algorithm in the dtype of pos (bit exact).
+ * pos_dev: [np][3] float32 (pos_is_f64=0) or float64 (1).                        */
+int vps_cell_index(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, int64_t np,
+                   int N, double Lbox, int32_t* cell_dev /* [np][3] */);
+/* payload_dev: [np][C] float32.  grid_dev: [C][nx][N][N] float32, ACCUMULATED into
+ * (caller zeroes it); particles whose x cell is outside [x0,x0+nx) are skipped.   */
+int vps_deposit_ngp(vps_ctx* ctx, const void* pos_dev, int pos_is_f64,
+                    const float* payload_dev, int64_t np, int C,
+                    int N, double Lbox, int x0, int nx, float* grid_dev);
+
+/* out_dev[np][4] = [vx*rho, vy*rho, vz*rho, rho]: GasParticles.density_velocity_vector
+ * (vpower/interp.py:199-213).  vel_dev [np][3], rho_dev [np], float32.             */
+int vps_density_velocity_vector(vps_ctx* ctx, const float* vel_dev, const float* rho_dev,
+                                int64_t np, float* out_dev);
+
+/* ---- stage A2: exact nearest-neighbour resampling ------------------------ */
+/* Replaces ann_interpolate (vpower/interp.py:1018-1049; pyann k=1, eps=0) and the
+ * per-cell Annoy query loop (scripts/parallel_optimized.py:337-358), as EXACT 1-NN:
+ * squared distance ((qx-px)^2+(qy-py)^2)+(qz-pz)^2 in float64, lowest particle
+ * index on exact ties.  Query lattice = qx_host[i] x qy_host[j] x qz_host[k]
+ * (float64 host arrays, so both reference lattices are expressible: interp.py:1063
+ * and parallel_optimized.py:343-345).  Only x rows [x0,x0+nx) of the lattice are
+ * produced.  out_dev: [C][nx][nqy][nqz] float32 = payload of the NN;
+ * nn_idx_dev (may be NULL): [nx][nqy][nqz] int32.
+ * work_dev: vps_nn_workspace_bytes(np, pos_is_f64) bytes of scratch.              */
+size_t vps_nn_workspace_bytes(int64_t np, int pos_is_f64);
+int vps_nn_resample(vps_ctx* ctx, const void* pos_dev, int pos_is_f64,
+                    const float* payload_dev, int64_t np, int C,
+                    const double* qx_host, int nqx, const double* qy_host, int nqy,
+                    const double* qz_host, int nqz, int x0, int nx,
+                    float* out_dev, int32_t* nn_idx_dev, void* work_dev);
+
+/* ---- stage A3: field algebra ------------------------------------------- */
+/* chans_dev: [4][ncell] = rho*vx, rho*vy, rho*vz, rho (density_velocity_vector,
+ * interp.py:199-213, after deposit/resample).  In place:
+ *   VPS_VELOCITY: chans[0..2] = rho v / rho, 0 where rho==0 (interp.py:272, NaN->0
+ *                 as interp.py:329-331);
+ *   VPS_MOMENTUM: chans[0..2] = v * (rho*Lcell^3)            (interp.py:273,523-525);
+ *   VPS_ENERGY  : chans[0]    = (rho*Lcell^3)*(vx^2+vy^2+vz^2) (interp.py:546);
+ *   VPS_VM      : chans[0..2] = v, chans[3] = rho*Lcell^3   (BoxField, interp.py:272-275).
+ * With VPS_FLAG_INPUT_IS_VM the channels are taken as vx,vy,vz,mass instead.        */
+int vps_field_algebra(vps_ctx* ctx, int quantity, int flags, double Lcell,
+                      float* chans_dev, int64_t ncell);
+
+/* ---- stage B+C: 3-D R2C FFT, |f|^2, shell binning ------------------------ */
+/* Supported N: powers of two, 16 <= N <= 4096.                                   */
+int vps_fft_supported(int N);
+/* Binning tables (host pointers, copied):
+ *   k2_axis[N]   = fl(k*k) for k = 2*pi*fftfreq(N, Lcell)   (interp.py:1449,1460)
+ *   thr[nbins+1] : thr[i] = smallest double t with fl(sqrt(t)) >= edge[i] (i<nbins),
+ *                  thr[nbins] = smallest t with fl(sqrt(t)) > edge[nbins]; so that
+ *                  thr[i] <= s < thr[i+1]  <=>  edge[i] <= sqrt(s) < edge[i+1] with the
+ *                  last bin right-closed, i.e. numpy.histogram's rule
+ *                  (interp.py:1474-1477, parallel_optimized.py:181-182).
+ *   edge0, inv_spacing: a first guess b=(sqrt(s)-edge0)*inv_spacing, corrected with thr. */
+int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host,
+                    const double* thr_host, int nbins, double edge0, double inv_spacing);
+
+/* Local part of the transform on an x-slab: z pass (R2C) and y pass.
+ * field_dev: [nx][N][N] float32 real input (NOT modified).
+ * spec_dev : [N/2][N][nx] complex64 = F_zy[kz][ky][x]   (kz < N/2)
+ * nyq_dev  : [N][nx]      complex64 = F_zy[kz=N/2][ky][x]
+ * work_dev : vps_fft_workspace_bytes(N,nx) bytes.
+ * nx must be a multiple of 16 (or equal to N when N < 16... see vps_fft_supported). */
+size_t vps_fft_workspace_bytes(int N, int nx);
+int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev,
+               void* spec_dev, void* nyq_dev, void* work_dev);
+
+/* x pass over `nlines` lines of length N.  Line i is made of nseg segments of
+ * N/nseg contiguous complex64: element x of line i lives at
+ *   in_dev[(x / seglen) * seg_stride + i * seglen + (x % seglen)],  seglen = N/nseg
+ * (nseg=1: plain contiguous lines; nseg=G: the layout an all-to-all of G x-slabs
+ * leaves behind).  Line i has global mode indices ky = (line0+i) % N and
+ * kz = kz0 + (line0+i)/N.
+ * mode 0: accumulate w*|F|^2 (w = 1 for kz in {0,N/2}, else 2) into
+ *         psum_dev[nbins] (float64) and w into nsample_dev[nbins] (uint64) using
+ *         the tables of vps_set_binning;  replaces _pair_power+_hist_sample
+ *         (interp.py:1440-1482) / pair_power+hist_sample (parallel_optimized.py:145-190).
+ * mode 1: write the transformed lines to out_dev[i][kx] (complex64, contiguous).
+ * mode 2: out_dev[i][kx] (float32) += |F|^2, no binning (component sums of
+ *         _vector_power, interp.py:1386).                                           */
+int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0,
+              const void* in_dev, int nseg, int64_t seg_stride, int mode,
+              double* psum_dev, unsigned long long* nsample_dev, void* out_dev);
+
+/* Single-GPU convenience: full |F(k)|^2 binning of one real field.
+ * field_dev [N][N][N] float32 is preserved; work_dev: vps_power_workspace_bytes(N). */
+size_t vps_power_workspace_bytes(int N);
+int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev,
+                  double* psum_dev, unsigned long long* nsample_dev);
+/* Single-GPU half spectrum for the un-binned API (_vector_power/_scalar_power,
+ * interp.py:1372-1421): out_dev [N/2+1][N][N] complex64 = F[kz][ky][kx].          */
+int vps_rfft3(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, void* out_dev);
+/* Same transform, but power_dev [N/2+1][N][N] float32 += |F[kz][ky][kx]|^2 (caller zeroes
+ * it; several components accumulate): the un-binned P grid of _vector_power.       */
+int vps_power_grid(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, float* power_dev);
+
+/* ---- un-fused binning API (not on the hot path) --------------------------- */
+/* out_dev[N^3] float64 = sqrt(kx*kx + ky*ky + kz*kz) over the meshgrid of the host axes,
+ * C order 'ij': column 0 of _pair_power (interp.py:1449-1462); the three axes are
+ * separate so that the per-axis shift of interp.py:1453-1458 can be applied.        */
+int vps_pair_k(vps_ctx* ctx, int N, const double* kx_host, const double* ky_host,
+               const double* kz_host, double* out_dev);
+/* numpy.histogram(k, bins=edges, weights=w) and the unweighted counts in one pass:
+ * edges[i] <= k < edges[i+1], last bin right-closed (interp.py:1474-1477).
+ * k_dev, w_dev: float64[n] (w_dev may be NULL: weights 1); edges_host[nbins+1];
+ * psum_dev float64[nbins] and nsample_dev uint64[nbins] are accumulated into.  Blocks. */
+int vps_hist_pairs(vps_ctx* ctx, const double* k_dev, const double* w_dev, int64_t n,
+                   const double* edges_host, int nbins, double* psum_dev,
+                   unsigned long long* nsample_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPS_HIP_H */

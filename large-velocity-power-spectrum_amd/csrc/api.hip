@@ -1,0 +1,211 @@
+// Context, memory, timing and binning-table entry points of the C ABI.
+#include <cstdarg>
+
+#include "vps_internal.h"
+
+static char g_last_error[512] = "no error";
+
+int vps_fail(vps_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) {
+    strncpy(ctx->err, buf, sizeof(ctx->err) - 1);
+    ctx->err[sizeof(ctx->err) - 1] = 0;
+  }
+  strncpy(g_last_error, buf, sizeof(g_last_error) - 1);
+  g_last_error[sizeof(g_last_error) - 1] = 0;
+  return code;
+}
+
+vps_launch_timer::vps_launch_timer(vps_ctx* c, int kind) : ctx(c) {
+  if (!ctx->timing) return;
+  vps_timed_launch tl;
+  tl.kind = kind;
+  hipEvent_t ev[2];
+  for (int i = 0; i < 2; ++i) {
+    if (!ctx->event_pool.empty()) {
+      ev[i] = ctx->event_pool.back();
+      ctx->event_pool.pop_back();
+    } else if (hipEventCreate(&ev[i]) != hipSuccess) {
+      return;
+    }
+  }
+  tl.start = ev[0];
+  tl.stop = ev[1];
+  (void)hipEventRecord(tl.start, ctx->stream);
+  ctx->launches.push_back(tl);
+  idx = (int)ctx->launches.size() - 1;
+}
+
+vps_launch_timer::~vps_launch_timer() {
+  if (idx >= 0) (void)hipEventRecord(ctx->launches[idx].stop, ctx->stream);
+}
+
+extern "C" {
+
+int vps_version(void) { return 1; }
+
+int vps_create(vps_ctx** out, int device_id) {
+  if (!out) return vps_fail(nullptr, VPS_ERR_ARG, "vps_create: null out pointer");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1)
+    return vps_fail(nullptr, VPS_ERR_HIP, "vps_create: no HIP device visible (%s)",
+                    e == hipSuccess ? "count=0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev)
+    return vps_fail(nullptr, VPS_ERR_ARG, "vps_create: device %d of %d", device_id, ndev);
+  e = hipSetDevice(device_id);
+  if (e != hipSuccess) return vps_fail(nullptr, VPS_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+  vps_ctx* ctx = new (std::nothrow) vps_ctx();
+  if (!ctx) return vps_fail(nullptr, VPS_ERR_NOMEM, "vps_create: out of host memory");
+  ctx->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (prop.maxSharedMemoryPerMultiProcessor > 0) ctx->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+  }
+  strcpy(ctx->err, "no error");
+  *out = ctx;
+  return VPS_OK;
+}
+
+int vps_destroy(vps_ctx* ctx) {
+  if (!ctx) return VPS_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  vps_fft_free_tables(ctx);
+  if (ctx->d_k2) (void)hipFree(ctx->d_k2);
+  if (ctx->d_thr) (void)hipFree(ctx->d_thr);
+  if (ctx->d_axes) (void)hipFree(ctx->d_axes);
+  for (auto& l : ctx->launches) {
+    (void)hipEventDestroy(l.start);
+    (void)hipEventDestroy(l.stop);
+  }
+  for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
+  delete ctx;
+  return VPS_OK;
+}
+
+const char* vps_last_error(const vps_ctx* ctx) { return ctx ? ctx->err : g_last_error; }
+
+int vps_set_stream(vps_ctx* ctx, void* hip_stream) {
+  if (!ctx) return VPS_ERR_ARG;
+  ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return VPS_OK;
+}
+
+int vps_sync(vps_ctx* ctx) {
+  if (!ctx) return VPS_ERR_ARG;
+  VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return VPS_OK;
+}
+
+int vps_device_info(vps_ctx* ctx, int64_t out[4]) {
+  if (!ctx || !out) return VPS_ERR_ARG;
+  hipDeviceProp_t prop;
+  VPS_HIP_CHECK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  out[0] = prop.multiProcessorCount;
+  out[1] = (int64_t)prop.maxSharedMemoryPerMultiProcessor;
+  out[2] = prop.warpSize;
+  out[3] = (int64_t)(prop.totalGlobalMem >> 20);
+  return VPS_OK;
+}
+
+int vps_malloc(vps_ctx* ctx, void** dev, size_t bytes) {
+  if (!ctx || !dev) return VPS_ERR_ARG;
+  *dev = nullptr;
+  hipError_t e = hipMalloc(dev, bytes ? bytes : 1);
+  if (e == hipErrorOutOfMemory) return vps_fail(ctx, VPS_ERR_NOMEM, "hipMalloc(%zu) out of memory", bytes);
+  VPS_HIP_CHECK(ctx, e);
+  return VPS_OK;
+}
+
+int vps_free(vps_ctx* ctx, void* dev) {
+  if (!ctx) return VPS_ERR_ARG;
+  if (dev) VPS_HIP_CHECK(ctx, hipFree(dev));
+  return VPS_OK;
+}
+
+int vps_memset(vps_ctx* ctx, void* dev, int value, size_t bytes) {
+  if (!ctx || (!dev && bytes)) return VPS_ERR_ARG;
+  if (bytes) VPS_HIP_CHECK(ctx, hipMemsetAsync(dev, value, bytes, ctx->stream));
+  return VPS_OK;
+}
+
+int vps_memcpy_h2d(vps_ctx* ctx, void* dev, const void* host, size_t bytes) {
+  if (!ctx || ((!dev || !host) && bytes)) return VPS_ERR_ARG;
+  if (bytes) VPS_HIP_CHECK(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return VPS_OK;
+}
+
+int vps_memcpy_d2h(vps_ctx* ctx, void* host, const void* dev, size_t bytes) {
+  if (!ctx || ((!dev || !host) && bytes)) return VPS_ERR_ARG;
+  if (bytes) VPS_HIP_CHECK(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return VPS_OK;
+}
+
+int vps_timing_enable(vps_ctx* ctx, int on) {
+  if (!ctx) return VPS_ERR_ARG;
+  ctx->timing = on != 0;
+  return VPS_OK;
+}
+
+int vps_timing_reset(vps_ctx* ctx) {
+  if (!ctx) return VPS_ERR_ARG;
+  VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& l : ctx->launches) {
+    ctx->event_pool.push_back(l.start);
+    ctx->event_pool.push_back(l.stop);
+  }
+  ctx->launches.clear();
+  return VPS_OK;
+}
+
+int vps_timing_get(vps_ctx* ctx, int kind, int64_t* launches, double* total_ms) {
+  if (!ctx || kind < 0 || kind >= VPS_K_COUNT) return VPS_ERR_ARG;
+  VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  int64_t n = 0;
+  double ms = 0.0;
+  for (auto& l : ctx->launches) {
+    if (l.kind != kind) continue;
+    float t = 0.f;
+    VPS_HIP_CHECK(ctx, hipEventElapsedTime(&t, l.start, l.stop));
+    ms += t;
+    ++n;
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  return VPS_OK;
+}
+
+int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const double* thr_host,
+                    int nbins, double edge0, double inv_spacing) {
+  if (!ctx) return VPS_ERR_ARG;
+  if (N < 2 || nbins < 1 || !k2_axis_host || !thr_host)
+    return vps_fail(ctx, VPS_ERR_ARG, "vps_set_binning: bad arguments (N=%d nbins=%d)", N, nbins);
+  if (nbins > 8192) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "nbins=%d > 8192", nbins);
+  for (int i = 0; i < nbins; ++i)
+    if (!(thr_host[i] <= thr_host[i + 1]))
+      return vps_fail(ctx, VPS_ERR_ARG, "vps_set_binning: thresholds must be non-decreasing (i=%d)", i);
+  // the x pass may still be reading the old tables
+  VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->d_k2) VPS_HIP_CHECK(ctx, hipFree(ctx->d_k2));
+  if (ctx->d_thr) VPS_HIP_CHECK(ctx, hipFree(ctx->d_thr));
+  ctx->d_k2 = ctx->d_thr = nullptr;
+  VPS_HIP_CHECK(ctx, hipMalloc(&ctx->d_k2, sizeof(double) * N));
+  VPS_HIP_CHECK(ctx, hipMalloc(&ctx->d_thr, sizeof(double) * (nbins + 1)));
+  VPS_HIP_CHECK(ctx, hipMemcpy(ctx->d_k2, k2_axis_host, sizeof(double) * N, hipMemcpyHostToDevice));
+  VPS_HIP_CHECK(ctx, hipMemcpy(ctx->d_thr, thr_host, sizeof(double) * (nbins + 1), hipMemcpyHostToDevice));
+  ctx->bin_N = N;
+  ctx->nbins = nbins;
+  ctx->edge0 = edge0;
+  ctx->inv_spacing = inv_spacing;
+  return VPS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,778 @@
+// 3-D real-to-complex FFT as three batched Stockham line passes, hand-written for
+// gfx950 (wave64, 160 KiB LDS/CU), with |F|^2 + spherical-shell binning fused into
+// the last pass.  No rocFFT/hipFFT.
+//
+// Replaces, on the device, the reference's pyFFTW calls and numpy histogram passes:
+//   _vector_power / _scalar_power        vpower/interp.py:1372-1387, 1408-1421
+//   FFTW_power / FFTW_vector_power       scripts/parallel_optimized.py:92-141
+//   _pair_power + _hist_sample           vpower/interp.py:1440-1482
+//   pair_power + hist_sample             scripts/parallel_optimized.py:145-190
+//
+// Data layout (all complex64 unless noted), N = cells per axis, nx = local x rows:
+//   input      R[x][y][z]        float32, z contiguous
+//   z pass  -> B[x][kz][y]       kz < N/2, y contiguous   (+ Nyquist plane BN[x][y])
+//   y pass  -> C[kz][ky][x]      x contiguous             (+ CN[ky][x])
+//   x pass  -> lines C[kz][ky][:] transformed in registers and binned (or written).
+// Every pass reads whole contiguous lines and writes T-element (T*8 byte) contiguous
+// segments of the next layout, so no pass ever does element-strided HBM access.
+//
+// One line of NC complex points is transformed by L lanes holding RL = NC/L points
+// each; radix-8/16 butterflies run in registers and the stages exchange data through
+// a padded per-line LDS buffer (Stockham autosort: stage inputs are always read at
+// stride NC/R, outputs written at expand(j)+r*Ns).
+#include "vps_internal.h"
+
+namespace {
+
+typedef float2 cf;
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// multiply by -i
+__device__ __forceinline__ cf cmul_mi(cf a) { return make_float2(a.y, -a.x); }
+
+#define VPS_SQRT1_2 0.70710678118654752440f
+#define VPS_COS_PI_8 0.92387953251128675613f
+#define VPS_SIN_PI_8 0.38268343236508977173f
+
+// ---- small DFTs on registers, forward sign exp(-2 pi i nk/R), natural order ----
+template <int R>
+struct Dft;
+
+template <>
+struct Dft<1> {
+  static __device__ __forceinline__ void run(cf*) {}
+};
+template <>
+struct Dft<2> {
+  static __device__ __forceinline__ void run(cf* v) {
+    cf a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+  }
+};
+template <>
+struct Dft<4> {
+  static __device__ __forceinline__ void run(cf* v) {
+    cf t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+    cf t2 = cadd(v[1], v[3]), t3 = cmul_mi(csub(v[1], v[3]));
+    v[0] = cadd(t0, t2);
+    v[1] = cadd(t1, t3);
+    v[2] = csub(t0, t2);
+    v[3] = csub(t1, t3);
+  }
+};
+template <>
+struct Dft<8> {
+  static __device__ __forceinline__ void run(cf* v) {
+    cf e[4] = {v[0], v[2], v[4], v[6]};
+    cf o[4] = {v[1], v[3], v[5], v[7]};
+    Dft<4>::run(e);
+    Dft<4>::run(o);
+    // o[k] *= w8^k
+    cf o1 = make_float2((o[1].x + o[1].y) * VPS_SQRT1_2, (o[1].y - o[1].x) * VPS_SQRT1_2);
+    cf o2 = cmul_mi(o[2]);
+    cf o3 = make_float2((o[3].y - o[3].x) * VPS_SQRT1_2, -(o[3].x + o[3].y) * VPS_SQRT1_2);
+    v[0] = cadd(e[0], o[0]);
+    v[4] = csub(e[0], o[0]);
+    v[1] = cadd(e[1], o1);
+    v[5] = csub(e[1], o1);
+    v[2] = cadd(e[2], o2);
+    v[6] = csub(e[2], o2);
+    v[3] = cadd(e[3], o3);
+    v[7] = csub(e[3], o3);
+  }
+};
+template <>
+struct Dft<16> {
+  static __device__ __forceinline__ void run(cf* v) {
+    // n = 4*n1 + n2, k = k1 + 4*k2
+    cf y[4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) {
+      cf t[4] = {v[n2], v[4 + n2], v[8 + n2], v[12 + n2]};
+      Dft<4>::run(t);
+#pragma unroll
+      for (int k1 = 0; k1 < 4; ++k1) y[n2][k1] = t[k1];
+    }
+    // twiddles w16^(n2*k1)
+    const cf w1 = make_float2(VPS_COS_PI_8, -VPS_SIN_PI_8);
+    const cf w2 = make_float2(VPS_SQRT1_2, -VPS_SQRT1_2);
+    const cf w3 = make_float2(VPS_SIN_PI_8, -VPS_COS_PI_8);
+    const cf w6 = make_float2(-VPS_SQRT1_2, -VPS_SQRT1_2);
+    const cf w9 = make_float2(-VPS_COS_PI_8, VPS_SIN_PI_8);
+    y[1][1] = cmul(y[1][1], w1);
+    y[1][2] = cmul(y[1][2], w2);
+    y[1][3] = cmul(y[1][3], w3);
+    y[2][1] = cmul(y[2][1], w2);
+    y[2][2] = cmul_mi(y[2][2]);
+    y[2][3] = cmul(y[2][3], w6);
+    y[3][1] = cmul(y[3][1], w3);
+    y[3][2] = cmul(y[3][2], w6);
+    y[3][3] = cmul(y[3][3], w9);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+      cf t[4] = {y[0][k1], y[1][k1], y[2][k1], y[3][k1]};
+      Dft<4>::run(t);
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = t[k2];
+    }
+  }
+};
+
+// ---- per-length plans: L lanes per line, radices R0*R1*R2 = NC -----------------
+template <int NC>
+struct Plan;
+#define VPS_PLAN(NC_, L_, A_, B_, C_)                          \
+  template <>                                                  \
+  struct Plan<NC_> {                                           \
+    static constexpr int L = L_, R0 = A_, R1 = B_, R2 = C_;    \
+  };
+VPS_PLAN(8, 1, 8, 1, 1)
+VPS_PLAN(16, 1, 16, 1, 1)
+VPS_PLAN(32, 4, 8, 4, 1)
+VPS_PLAN(64, 8, 8, 8, 1)
+VPS_PLAN(128, 8, 16, 8, 1)
+VPS_PLAN(256, 16, 16, 16, 1)
+VPS_PLAN(512, 32, 8, 8, 8)
+VPS_PLAN(1024, 64, 16, 8, 8)
+VPS_PLAN(2048, 128, 16, 16, 8)
+VPS_PLAN(4096, 256, 16, 16, 16)
+
+template <int NC>
+struct PlanInfo {
+  typedef Plan<NC> P;
+  static constexpr int L = P::L;
+  static constexpr int RL = NC / L;
+  static constexpr int R0 = P::R0, R1 = P::R1, R2 = P::R2;
+  static constexpr int NS1 = R0, NS2 = R0 * R1;
+  static constexpr int TW1 = (R1 > 1) ? (R1 - 1) * NS1 : 0;
+  static constexpr int TW2 = (R2 > 1) ? (R2 - 1) * NS2 : 0;
+  static constexpr int TW = TW1 + TW2;  // entries of the per-stage twiddle image
+  // LDS line pitch (complex elements): one pad slot per 32 elements
+  static constexpr int PITCH = NC + (NC >> 5) + 1;
+  static_assert(R0 * R1 * R2 == NC, "bad plan");
+  static_assert(RL % R0 == 0 && RL % R1 == 0 && RL % R2 == 0, "radix must divide RL");
+};
+
+__device__ __forceinline__ int padidx(int p) { return p + (p >> 5); }
+
+// Transposed tile image [k][t] with pitch T and an XOR swizzle of t, so that both the
+// column-wise writes (16 consecutive k, one t) and the row-wise reads (one k, all t)
+// of ds_write_b64 / ds_read_b64 touch distinct LDS slots.
+template <int T>
+__device__ __forceinline__ int tridx(int k, int t) {
+  constexpr int SH = (T >= 16) ? 0 : ((T == 8) ? 1 : ((T == 4) ? 2 : ((T == 2) ? 3 : 4)));
+  return k * T + (t ^ ((k >> SH) & (T - 1)));
+}
+
+// Stage s input for lane l: v[m*R + r] = src(l + L*m + r*NC/R)
+template <int NC, int L, int RL, int R>
+__device__ __forceinline__ void lds_load_stage(cf (&v)[RL], const cf* line, int l) {
+  constexpr int NB = RL / R;
+#pragma unroll
+  for (int m = 0; m < NB; ++m) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[m * R + r] = line[padidx(l + L * m + r * (NC / R))];
+  }
+}
+
+template <int NC, int L, int RL, int R, int NS>
+__device__ __forceinline__ void twiddle_butterfly(cf (&v)[RL], const cf* tw, int l) {
+  constexpr int NB = RL / R;
+#pragma unroll
+  for (int m = 0; m < NB; ++m) {
+    if constexpr (NS > 1) {
+      const int k = (l + L * m) & (NS - 1);
+#pragma unroll
+      for (int r = 1; r < R; ++r) v[m * R + r] = cmul(v[m * R + r], tw[(r - 1) * NS + k]);
+    }
+    Dft<R>::run(&v[m * R]);
+  }
+}
+
+template <int NC, int L, int RL, int R, int NS>
+__device__ __forceinline__ void lds_store_stage(const cf (&v)[RL], cf* line, int l) {
+  constexpr int NB = RL / R;
+#pragma unroll
+  for (int m = 0; m < NB; ++m) {
+    const int j = l + L * m;
+    const int k = j & (NS - 1);
+    const int j0 = (j - k) * R + k;
+#pragma unroll
+    for (int r = 0; r < R; ++r) line[padidx(j0 + r * NS)] = v[m * R + r];
+  }
+}
+
+// Runs stages 1.. (stage 0 inputs already in v).  On return v holds the spectrum:
+// v[m*RLAST + r] = F[l + L*m + r*NC/RLAST].
+template <int NC>
+__device__ __forceinline__ void fft_from_regs(cf (&v)[PlanInfo<NC>::RL], cf* line, const cf* tw,
+                                              int l) {
+  typedef PlanInfo<NC> PI;
+  constexpr int L = PI::L, RL = PI::RL;
+  twiddle_butterfly<NC, L, RL, PI::R0, 1>(v, tw, l);
+  if constexpr (PI::R1 > 1) {
+    lds_store_stage<NC, L, RL, PI::R0, 1>(v, line, l);
+    __syncthreads();
+    lds_load_stage<NC, L, RL, PI::R1>(v, line, l);
+    twiddle_butterfly<NC, L, RL, PI::R1, PI::NS1>(v, tw, l);
+    if constexpr (PI::R2 > 1) {
+      __syncthreads();
+      lds_store_stage<NC, L, RL, PI::R1, PI::NS1>(v, line, l);
+      __syncthreads();
+      lds_load_stage<NC, L, RL, PI::R2>(v, line, l);
+      twiddle_butterfly<NC, L, RL, PI::R2, PI::NS2>(v, tw + PI::TW1, l);
+    }
+  }
+}
+
+template <int NC>
+struct LastRadix {
+  typedef PlanInfo<NC> PI;
+  static constexpr int R = (PI::R2 > 1) ? PI::R2 : ((PI::R1 > 1) ? PI::R1 : PI::R0);
+};
+
+// output index of register slot i = m*R + r after the last stage
+template <int NC>
+__device__ __forceinline__ int out_index(int l, int i) {
+  constexpr int R = LastRadix<NC>::R;
+  constexpr int L = PlanInfo<NC>::L;
+  const int m = i / R, r = i % R;
+  return l + L * m + r * (NC / R);
+}
+
+struct PassParams {
+  const void* in;
+  void* out;
+  void* out_nyq;
+  long long in_sa, in_sb;  // input strides of the tile axis a and batch axis b (elements)
+  long long out_ob, out_ok;  // output strides (complex elements): out[b*ob + k*ok + a]
+  long long nyq_ob;          // out_nyq[b*nyq_ob + a]
+  int A, B;                  // extent of tile axis / batch axis
+  const cf* tw_stage;
+  const cf* tw_r2c;
+};
+
+// ------------------------------------------------------------------------------
+// Transposing pass (z pass: REAL=true, y pass: REAL=false).
+// One workgroup transforms T lines a0..a0+T-1 of batch b and writes, for every
+// output index k, the T results to T contiguous complex slots out[b][k][a0..].
+// ------------------------------------------------------------------------------
+template <int NC, int T, bool REAL>
+__global__ void __launch_bounds__(T* PlanInfo<NC>::L)
+    fft_transpose_pass(const PassParams p) {
+  typedef PlanInfo<NC> PI;
+  constexpr int L = PI::L, RL = PI::RL, NT = T * L;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cf* tw = reinterpret_cast<cf*>(smem_raw);
+  cf* buf = tw + ((PI::TW + 1) & ~1);
+
+  const int tid = threadIdx.x;
+  const int t = tid / L, l = tid % L;
+  const int tiles = (p.A + T - 1) / T;
+  const int b = blockIdx.x / tiles;
+  const int a0 = (blockIdx.x % tiles) * T;
+
+  for (int i = tid; i < PI::TW; i += NT) tw[i] = p.tw_stage[i];
+
+  cf v[RL];
+  {
+    const bool live = (a0 + t) < p.A;
+    constexpr int R = PI::R0, NB = RL / R;
+    if constexpr (REAL) {
+      // line of 2*NC floats read as NC packed complex z[j] = x[2j] + i x[2j+1]
+      const cf* src = reinterpret_cast<const cf*>(reinterpret_cast<const float*>(p.in) +
+                                                   (long long)b * p.in_sb +
+                                                   (long long)(a0 + t) * p.in_sa);
+#pragma unroll
+      for (int m = 0; m < NB; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          v[m * R + r] = live ? src[l + L * m + r * (NC / R)] : make_float2(0.f, 0.f);
+    } else {
+      const cf* src = reinterpret_cast<const cf*>(p.in) + (long long)b * p.in_sb +
+                      (long long)(a0 + t) * p.in_sa;
+#pragma unroll
+      for (int m = 0; m < NB; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          v[m * R + r] = live ? src[l + L * m + r * (NC / R)] : make_float2(0.f, 0.f);
+    }
+  }
+  __syncthreads();  // twiddle image visible
+  fft_from_regs<NC>(v, buf + t * PI::PITCH, tw, l);
+  __syncthreads();  // every lane done with the per-line buffers
+  // transposed image [k][t]
+#pragma unroll
+  for (int i = 0; i < RL; ++i) buf[tridx<T>(out_index<NC>(l, i), t)] = v[i];
+  __syncthreads();
+
+  cf* out = reinterpret_cast<cf*>(p.out) + (long long)b * p.out_ob + a0;
+  if constexpr (!REAL) {
+#pragma unroll 4
+    for (int i = 0; i < RL; ++i) {
+      const int idx = tid + i * NT;
+      const int tt = idx % T, k = idx / T;
+      if (a0 + tt < p.A) out[(long long)k * p.out_ok + tt] = buf[tridx<T>(k, tt)];
+    }
+  } else {
+    // real-input post-processing: X[k] = 0.5*((Z[k]+conj(Z[NC-k])) - i w^k (Z[k]-conj(Z[NC-k])))
+    // with w = exp(-2 pi i/(2 NC)); X[0] and X[NC] (Nyquist) are real.
+    cf* nyq = reinterpret_cast<cf*>(p.out_nyq) + (long long)b * p.nyq_ob + a0;
+#pragma unroll 4
+    for (int i = 0; i < RL; ++i) {
+      const int idx = tid + i * NT;
+      const int tt = idx % T, k = idx / T;
+      const cf zk = buf[tridx<T>(k, tt)];
+      cf res;
+      if (k == 0) {
+        res = make_float2(zk.x + zk.y, 0.f);
+        if (a0 + tt < p.A) nyq[tt] = make_float2(zk.x - zk.y, 0.f);
+      } else {
+        const cf zn = buf[tridx<T>(NC - k, tt)];
+        const cf w = p.tw_r2c[k];
+        const cf s = make_float2(zk.x + zn.x, zk.y - zn.y);   // Z[k] + conj(Z[NC-k])
+        const cf d = make_float2(zk.x - zn.x, zk.y + zn.y);   // Z[k] - conj(Z[NC-k])
+        const cf wd = cmul(w, d);
+        // -i * wd = (wd.y, -wd.x)
+        res = make_float2(0.5f * (s.x + wd.y), 0.5f * (s.y - wd.x));
+      }
+      if (a0 + tt < p.A) out[(long long)k * p.out_ok + tt] = res;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
+// x pass: lines are contiguous (or made of nseg contiguous segments); the result is
+// binned straight from registers (MODE 0) or written in place order (MODE 1).
+// Persistent workgroups loop over tiles of T lines.
+// ------------------------------------------------------------------------------
+struct XParams {
+  const cf* in;
+  cf* out;
+  long long nlines, line0;
+  int N, kz0;
+  int seglen, seg_shift;  // segment length (a power of two) and its log2
+  long long seg_stride;
+  const cf* tw_stage;
+  const double* k2;
+  const double* thr;
+  int nbins;
+  float edge0, inv_spacing;
+  double* psum;
+  unsigned long long* nsample;
+};
+
+template <int NC, int T, int MODE, bool SEG>
+__global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p) {
+  typedef PlanInfo<NC> PI;
+  constexpr int L = PI::L, RL = PI::RL, NT = T * L;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // carve: thr (double) | hsum (double) | tw | line buffers | hcnt
+  double* thr = reinterpret_cast<double*>(smem_raw);
+  double* hsum = thr + (MODE == 0 ? (p.nbins + 1) : 0);
+  cf* tw = reinterpret_cast<cf*>(hsum + (MODE == 0 ? p.nbins : 0));
+  cf* buf = tw + ((PI::TW + 1) & ~1);
+  unsigned* hcnt = reinterpret_cast<unsigned*>(buf + T * PI::PITCH);
+
+  const int tid = threadIdx.x;
+  const int t = tid / L, l = tid % L;
+  for (int i = tid; i < PI::TW; i += NT) tw[i] = p.tw_stage[i];
+  if constexpr (MODE == 0) {
+    for (int i = tid; i <= p.nbins; i += NT) thr[i] = p.thr[i];
+    for (int i = tid; i < p.nbins; i += NT) {
+      hsum[i] = 0.0;
+      hcnt[i] = 0u;
+    }
+  }
+  __syncthreads();
+
+  cf* line = buf + t * PI::PITCH;
+  const int segmask = p.seglen - 1;
+  const long long ntiles = (p.nlines + T - 1) / T;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long li = tile * T + t;  // local line index
+    const bool live = li < p.nlines;
+    cf v[RL];
+    {
+      constexpr int R = PI::R0, NB = RL / R;
+      const cf* base = p.in + li * p.seglen;
+#pragma unroll
+      for (int m = 0; m < NB; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int x = l + L * m + r * (NC / R);
+          if constexpr (SEG) {
+            // element x of the line sits in segment x >> seg_shift at offset x & segmask
+            v[m * R + r] = live ? base[(long long)(x >> p.seg_shift) * p.seg_stride + (x & segmask)]
+                                : make_float2(0.f, 0.f);
+          } else {
+            v[m * R + r] = live ? base[x] : make_float2(0.f, 0.f);
+          }
+        }
+    }
+    __syncthreads();  // previous tile's readers are done with the line buffers
+    fft_from_regs<NC>(v, line, tw, l);
+    if constexpr (MODE == 1) {
+      if (live) {
+        cf* o = p.out + li * (long long)NC;
+#pragma unroll
+        for (int i = 0; i < RL; ++i) o[out_index<NC>(l, i)] = v[i];
+      }
+    } else if constexpr (MODE == 2) {
+      if (live) {
+        float* o = reinterpret_cast<float*>(p.out) + li * (long long)NC;
+#pragma unroll
+        for (int i = 0; i < RL; ++i) o[out_index<NC>(l, i)] += v[i].x * v[i].x + v[i].y * v[i].y;
+      }
+    } else {
+      // |F|^2 of the line goes through LDS so that the binning loop below is a small
+      // rolled loop over kx instead of RL unrolled copies
+      float* pw = reinterpret_cast<float*>(line);
+      if constexpr (PI::R1 > 1) __syncthreads();  // last exchange fully consumed
+#pragma unroll
+      for (int i = 0; i < RL; ++i) pw[out_index<NC>(l, i)] = v[i].x * v[i].x + v[i].y * v[i].y;
+      __syncthreads();
+      if (live) {
+        const long long g = p.line0 + li;
+        const int ky = (int)(g % p.N);
+        const int kz = p.kz0 + (int)(g / p.N);
+        const double k2y = p.k2[ky], k2z = p.k2[kz];
+        const unsigned w = (kz == 0 || 2 * kz == p.N) ? 1u : 2u;
+        const double wd = (double)w;
+        for (int kx = l; kx < NC; kx += L) {
+          // s = (kx*kx + ky*ky) + kz*kz with numpy's rounding (the table holds fl(k*k))
+          const double s = (p.k2[kx] + k2y) + k2z;
+          int bi = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
+          bi = min(max(bi, 0), p.nbins - 1);
+          while (bi > 0 && s < thr[bi]) --bi;
+          while (bi < p.nbins - 1 && s >= thr[bi + 1]) ++bi;
+          if (s >= thr[bi] && s < thr[bi + 1]) {
+            atomicAdd(&hsum[bi], (double)pw[kx] * wd);
+            atomicAdd(&hcnt[bi], w);
+          }
+        }
+      }
+    }
+  }
+  if constexpr (MODE == 0) {
+    __syncthreads();
+    for (int i = tid; i < p.nbins; i += NT) {
+      const unsigned c = hcnt[i];
+      if (c) {
+        atomicAdd(&p.psum[i], hsum[i]);
+        atomicAdd(&p.nsample[i], (unsigned long long)c);
+      }
+    }
+  }
+}
+
+template <int NC>
+constexpr int transpose_T() {
+  // tile width: 16 lines (128-byte output segments) while the LDS image fits,
+  // at least one full wave of threads for short lines
+  if (NC <= 16) return 64;
+  if (NC <= 512) return 16;
+  if (NC <= 2048) return 8;
+  return 4;
+}
+template <int NC>
+constexpr int xpass_T() {
+  constexpr int L = Plan<NC>::L;
+  return (256 / L) > 0 ? (256 / L) : 1;
+}
+
+template <int NC, int T>
+size_t transpose_lds_bytes() {
+  typedef PlanInfo<NC> PI;
+  size_t lines = (size_t)T * PI::PITCH;
+  size_t tr = (size_t)NC * T;
+  return (((PI::TW + 1) & ~1) + (lines > tr ? lines : tr)) * sizeof(cf);
+}
+
+template <int NC, bool REAL>
+int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
+  constexpr int T = transpose_T<NC>();
+  typedef PlanInfo<NC> PI;
+  const size_t lds = transpose_lds_bytes<NC, T>();
+  auto kern = fft_transpose_pass<NC, T, REAL>;
+  if (lds > 64 * 1024)
+    VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long long tiles = (p.A + T - 1) / T;
+  const long long grid = tiles * p.B;
+  if (grid <= 0 || grid > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_ARG, "fft grid out of range");
+  {
+    vps_launch_timer tm(ctx, kind);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(T * PI::L), lds, ctx->stream, p);
+  }
+  VPS_HIP_CHECK(ctx, hipGetLastError());
+  return VPS_OK;
+}
+
+template <int NC, int MODE>
+int launch_x(vps_ctx* ctx, const XParams& p) {
+  constexpr int T = xpass_T<NC>();
+  typedef PlanInfo<NC> PI;
+  size_t lds = (((PI::TW + 1) & ~1) + (size_t)T * PI::PITCH) * sizeof(cf);
+  if (MODE == 0) lds += (size_t)(2 * p.nbins + 1) * sizeof(double) + (size_t)p.nbins * sizeof(unsigned);
+  if (lds > ctx->lds_per_cu) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "x pass needs %zu B LDS", lds);
+  const bool seg = p.seglen != NC;
+  auto kern = seg ? fft_x_pass<NC, T, MODE, true> : fft_x_pass<NC, T, MODE, false>;
+  if (lds > 64 * 1024)
+    VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long long ntiles = (p.nlines + T - 1) / T;
+  long long per_cu = (long long)(ctx->lds_per_cu / (lds ? lds : 1));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  long long grid = (long long)ctx->num_cu * per_cu;
+  if (grid > ntiles) grid = ntiles;
+  if (grid < 1) return VPS_OK;
+  {
+    vps_launch_timer tm(ctx, VPS_K_FFT_X);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(T * PI::L), lds, ctx->stream, p);
+  }
+  VPS_HIP_CHECK(ctx, hipGetLastError());
+  return VPS_OK;
+}
+
+#define VPS_DISPATCH_NC(NCVAL, CALL)                                  \
+  switch (NCVAL) {                                                    \
+    case 8: { constexpr int NC_ = 8; CALL; } break;                   \
+    case 16: { constexpr int NC_ = 16; CALL; } break;                 \
+    case 32: { constexpr int NC_ = 32; CALL; } break;                 \
+    case 64: { constexpr int NC_ = 64; CALL; } break;                 \
+    case 128: { constexpr int NC_ = 128; CALL; } break;               \
+    case 256: { constexpr int NC_ = 256; CALL; } break;               \
+    case 512: { constexpr int NC_ = 512; CALL; } break;               \
+    case 1024: { constexpr int NC_ = 1024; CALL; } break;             \
+    case 2048: { constexpr int NC_ = 2048; CALL; } break;             \
+    case 4096: { constexpr int NC_ = 4096; CALL; } break;             \
+    default: rc = vps_fail(ctx, VPS_ERR_UNSUPPORTED, "unsupported FFT length %d", (int)(NCVAL)); \
+  }
+
+// host-side twiddle image for complex length NC (double precision, rounded once)
+template <int NC>
+void build_stage_tw(std::vector<cf>& out) {
+  typedef PlanInfo<NC> PI;
+  out.assign(PI::TW > 0 ? PI::TW : 1, make_float2(1.f, 0.f));
+  const double tp = -2.0 * 3.14159265358979323846;
+  if (PI::R1 > 1)
+    for (int r = 1; r < PI::R1; ++r)
+      for (int k = 0; k < PI::NS1; ++k) {
+        double a = tp * (double)r * (double)k / (double)(PI::NS1 * PI::R1);
+        out[(r - 1) * PI::NS1 + k] = make_float2((float)cos(a), (float)sin(a));
+      }
+  if (PI::R2 > 1)
+    for (int r = 1; r < PI::R2; ++r)
+      for (int k = 0; k < PI::NS2; ++k) {
+        double a = tp * (double)r * (double)k / (double)(PI::NS2 * PI::R2);
+        out[PI::TW1 + (r - 1) * PI::NS2 + k] = make_float2((float)cos(a), (float)sin(a));
+      }
+}
+
+}  // namespace
+
+int vps_fft_get_tables(vps_ctx* ctx, int NC, vps_fft_tables* out) {
+  auto it = ctx->fft_tables.find(NC);
+  if (it != ctx->fft_tables.end()) {
+    *out = it->second;
+    return VPS_OK;
+  }
+  std::vector<cf> st;
+  int rc = VPS_OK;
+  VPS_DISPATCH_NC(NC, build_stage_tw<NC_>(st));
+  if (rc) return rc;
+  std::vector<cf> r2c(NC);
+  for (int k = 0; k < NC; ++k) {
+    double a = -2.0 * 3.14159265358979323846 * (double)k / (double)(2 * NC);
+    r2c[k] = make_float2((float)cos(a), (float)sin(a));
+  }
+  vps_fft_tables t;
+  VPS_HIP_CHECK(ctx, hipMalloc(&t.tw_stage, st.size() * sizeof(cf)));
+  VPS_HIP_CHECK(ctx, hipMalloc(&t.tw_r2c, r2c.size() * sizeof(cf)));
+  VPS_HIP_CHECK(ctx, hipMemcpy(t.tw_stage, st.data(), st.size() * sizeof(cf), hipMemcpyHostToDevice));
+  VPS_HIP_CHECK(ctx, hipMemcpy(t.tw_r2c, r2c.data(), r2c.size() * sizeof(cf), hipMemcpyHostToDevice));
+  ctx->fft_tables[NC] = t;
+  *out = t;
+  return VPS_OK;
+}
+
+void vps_fft_free_tables(vps_ctx* ctx) {
+  for (auto& kv : ctx->fft_tables) {
+    (void)hipFree(kv.second.tw_stage);
+    (void)hipFree(kv.second.tw_r2c);
+  }
+  ctx->fft_tables.clear();
+}
+
+extern "C" {
+
+int vps_fft_supported(int N) { return (N >= 16 && N <= 4096 && (N & (N - 1)) == 0) ? 1 : 0; }
+
+size_t vps_fft_workspace_bytes(int N, int nx) {
+  // B[x][kz][y] (kz < N/2) + Nyquist plane BN[x][y]
+  return ((size_t)nx * (size_t)(N / 2) * (size_t)N + (size_t)nx * (size_t)N) * sizeof(cf);
+}
+
+size_t vps_power_workspace_bytes(int N) {
+  // z-pass image + y-pass image (each with its Nyquist plane)
+  return 2 * vps_fft_workspace_bytes(N, N);
+}
+
+int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev, void* spec_dev, void* nyq_dev,
+               void* work_dev) {
+  if (!ctx) return VPS_ERR_ARG;
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096]", N);
+  if (nx < 1 || nx > N) return vps_fail(ctx, VPS_ERR_ARG, "nx=%d out of range", nx);
+  if (!field_dev || !spec_dev || !nyq_dev || !work_dev) return vps_fail(ctx, VPS_ERR_ARG, "null buffer");
+  const int NH = N / 2;
+  vps_fft_tables tz, ty;
+  int rc = vps_fft_get_tables(ctx, NH, &tz);
+  if (rc) return rc;
+  rc = vps_fft_get_tables(ctx, N, &ty);
+  if (rc) return rc;
+  cf* B = reinterpret_cast<cf*>(work_dev);
+  cf* BN = B + (size_t)nx * NH * N;
+
+  // z pass: lines (a = y, b = x) of R[x][y][:] -> B[x][kz][y], BN[x][y]
+  PassParams pz{};
+  pz.in = field_dev;
+  pz.out = B;
+  pz.out_nyq = BN;
+  pz.in_sa = N;
+  pz.in_sb = (long long)N * N;
+  pz.out_ob = (long long)NH * N;
+  pz.out_ok = N;
+  pz.nyq_ob = N;
+  pz.A = N;
+  pz.B = nx;
+  pz.tw_stage = tz.tw_stage;
+  pz.tw_r2c = tz.tw_r2c;
+  VPS_DISPATCH_NC(NH, (rc = launch_transpose<NC_, true>(ctx, pz, VPS_K_FFT_Z)));
+  if (rc) return rc;
+
+  // y pass: lines (a = x, b = kz) of B[x][kz][:] -> C[kz][ky][x]
+  PassParams py{};
+  py.in = B;
+  py.out = spec_dev;
+  py.in_sa = (long long)NH * N;
+  py.in_sb = N;
+  py.out_ob = (long long)N * nx;
+  py.out_ok = nx;
+  py.A = nx;
+  py.B = NH;
+  py.tw_stage = ty.tw_stage;
+  VPS_DISPATCH_NC(N, (rc = launch_transpose<NC_, false>(ctx, py, VPS_K_FFT_Y)));
+  if (rc) return rc;
+  // Nyquist plane: lines (a = x, b = 0) of BN[x][:] -> CN[ky][x]
+  PassParams pn = py;
+  pn.in = BN;
+  pn.out = nyq_dev;
+  pn.in_sa = N;
+  pn.in_sb = 0;
+  pn.out_ob = 0;
+  pn.B = 1;
+  VPS_DISPATCH_NC(N, (rc = launch_transpose<NC_, false>(ctx, pn, VPS_K_FFT_Y)));
+  return rc;
+}
+
+int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const void* in_dev,
+              int nseg, int64_t seg_stride, int mode, double* psum_dev,
+              unsigned long long* nsample_dev, void* out_dev) {
+  if (!ctx) return VPS_ERR_ARG;
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096]", N);
+  if (nlines < 0 || !in_dev) return vps_fail(ctx, VPS_ERR_ARG, "bad line count / null input");
+  if (nseg < 1 || N % nseg) return vps_fail(ctx, VPS_ERR_ARG, "nseg=%d must divide N", nseg);
+  if (nlines == 0) return VPS_OK;
+  vps_fft_tables tx;
+  int rc = vps_fft_get_tables(ctx, N, &tx);
+  if (rc) return rc;
+  XParams p{};
+  p.in = reinterpret_cast<const cf*>(in_dev);
+  p.out = reinterpret_cast<cf*>(out_dev);
+  p.nlines = nlines;
+  p.line0 = line0;
+  p.N = N;
+  p.kz0 = kz0;
+  p.seglen = N / nseg;
+  p.seg_shift = 0;
+  while ((1 << p.seg_shift) < p.seglen) ++p.seg_shift;
+  if ((1 << p.seg_shift) != p.seglen) return vps_fail(ctx, VPS_ERR_ARG, "nseg=%d must be a power of two", nseg);
+  p.seg_stride = seg_stride;
+  p.tw_stage = tx.tw_stage;
+  if (mode == 0) {
+    if (ctx->bin_N != N || !ctx->d_k2) return vps_fail(ctx, VPS_ERR_ARG, "vps_set_binning(N=%d) has not been called", N);
+    if (!psum_dev || !nsample_dev) return vps_fail(ctx, VPS_ERR_ARG, "null accumulator");
+    const long long maxline = line0 + nlines - 1;
+    if (kz0 + (int)(maxline / N) > N / 2) return vps_fail(ctx, VPS_ERR_ARG, "kz range exceeds N/2");
+    p.k2 = ctx->d_k2;
+    p.thr = ctx->d_thr;
+    p.nbins = ctx->nbins;
+    p.edge0 = (float)ctx->edge0;
+    p.inv_spacing = (float)ctx->inv_spacing;
+    p.psum = psum_dev;
+    p.nsample = nsample_dev;
+    VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 0>(ctx, p)));
+  } else if (mode == 1) {
+    if (!out_dev) return vps_fail(ctx, VPS_ERR_ARG, "null output");
+    VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 1>(ctx, p)));
+  } else if (mode == 2) {
+    if (!out_dev) return vps_fail(ctx, VPS_ERR_ARG, "null output");
+    VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 2>(ctx, p)));
+  } else {
+    return vps_fail(ctx, VPS_ERR_ARG, "mode must be 0, 1 or 2");
+  }
+  return rc;
+}
+
+int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, double* psum_dev,
+                  unsigned long long* nsample_dev) {
+  if (!ctx) return VPS_ERR_ARG;
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096]", N);
+  const size_t half = vps_fft_workspace_bytes(N, N);
+  char* w = reinterpret_cast<char*>(work_dev);
+  cf* spec = reinterpret_cast<cf*>(w + half);
+  cf* nyq = spec + (size_t)(N / 2) * N * N;
+  int rc = vps_fft_zy(ctx, N, N, field_dev, spec, nyq, w);
+  if (rc) return rc;
+  rc = vps_fft_x(ctx, N, (int64_t)(N / 2) * N, 0, 0, spec, 1, 0, 0, psum_dev, nsample_dev, nullptr);
+  if (rc) return rc;
+  return vps_fft_x(ctx, N, N, 0, N / 2, nyq, 1, 0, 0, psum_dev, nsample_dev, nullptr);
+}
+
+int vps_rfft3(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, void* out_dev) {
+  if (!ctx) return VPS_ERR_ARG;
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096]", N);
+  const size_t half = vps_fft_workspace_bytes(N, N);
+  char* w = reinterpret_cast<char*>(work_dev);
+  cf* spec = reinterpret_cast<cf*>(w + half);
+  cf* nyq = spec + (size_t)(N / 2) * N * N;
+  int rc = vps_fft_zy(ctx, N, N, field_dev, spec, nyq, w);
+  if (rc) return rc;
+  cf* out = reinterpret_cast<cf*>(out_dev);
+  rc = vps_fft_x(ctx, N, (int64_t)(N / 2) * N, 0, 0, spec, 1, 0, 1, nullptr, nullptr, out);
+  if (rc) return rc;
+  return vps_fft_x(ctx, N, N, 0, N / 2, nyq, 1, 0, 1, nullptr, nullptr, out + (size_t)(N / 2) * N * N);
+}
+
+int vps_power_grid(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, float* power_dev) {
+  if (!ctx) return VPS_ERR_ARG;
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096]", N);
+  const size_t half = vps_fft_workspace_bytes(N, N);
+  char* w = reinterpret_cast<char*>(work_dev);
+  cf* spec = reinterpret_cast<cf*>(w + half);
+  cf* nyq = spec + (size_t)(N / 2) * N * N;
+  int rc = vps_fft_zy(ctx, N, N, field_dev, spec, nyq, w);
+  if (rc) return rc;
+  rc = vps_fft_x(ctx, N, (int64_t)(N / 2) * N, 0, 0, spec, 1, 0, 2, nullptr, nullptr, power_dev);
+  if (rc) return rc;
+  return vps_fft_x(ctx, N, N, 0, N / 2, nyq, 1, 0, 2, nullptr, nullptr, power_dev + (size_t)(N / 2) * N * N);
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+// Internal declarations shared by the translation units of libvps_hip.so.
+// Not part of the ABI (that is include/vps_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "../../include/vps_hip.h"
+
+struct vps_timed_launch {
+  int kind;
+  hipEvent_t start, stop;
+};
+
+struct vps_fft_tables {
+  float2* tw_stage = nullptr;  // per-stage LDS twiddle image for complex length NC
+  float2* tw_r2c = nullptr;    // exp(-2 pi i k / (2 NC)), k < NC  (real length 2 NC)
+};
+
+struct vps_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512] = {0};
+  int num_cu = 256;
+  size_t lds_per_cu = 160 * 1024;
+
+  std::map<int, vps_fft_tables> fft_tables;  // keyed by complex length NC
+
+  // binning tables (vps_set_binning)
+  int bin_N = 0;
+  int nbins = 0;
+  double* d_k2 = nullptr;   // [N]
+  double* d_thr = nullptr;  // [nbins+1]
+  double edge0 = 0.0, inv_spacing = 0.0;
+
+  // small device scratch for the NN lattice axes
+  double* d_axes = nullptr;
+  size_t axes_cap = 0;
+
+  bool timing = false;
+  std::vector<vps_timed_launch> launches;
+  std::vector<hipEvent_t> event_pool;
+};
+
+int vps_fail(vps_ctx* ctx, int code, const char* fmt, ...);
+
+#define VPS_HIP_CHECK(ctx, expr)                                                   \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess)                                                          \
+      return vps_fail((ctx), VPS_ERR_HIP, "%s failed: %s (%s:%d)", #expr,          \
+                      hipGetErrorString(_e), __FILE__, __LINE__);                  \
+  } while (0)
+
+// Brackets a kernel launch with events when ctx->timing is on.
+struct vps_launch_timer {
+  vps_ctx* ctx;
+  int idx = -1;
+  vps_launch_timer(vps_ctx* c, int kind);
+  ~vps_launch_timer();
+};
+
+// fft.hip
+int vps_fft_get_tables(vps_ctx* ctx, int NC, vps_fft_tables* out);
+void vps_fft_free_tables(vps_ctx* ctx);

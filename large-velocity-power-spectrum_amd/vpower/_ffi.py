@@ -1,0 +1,135 @@
+"""ctypes binding of libvps_hip.so (include/vps_hip.h).
+
+This is the only place the shared library is loaded.  There is NO CPU fallback: if the
+library is missing or a call fails the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+CSRC = os.path.join(PKG_ROOT, "csrc")
+LIB_PATH = os.path.join(_HERE, "libvps_hip.so")
+SOURCES = ("api.hip", "deposit.hip", "nn.hip", "fft.hip", "hist.hip")
+HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics")
+
+# every symbol include/vps_hip.h declares: (name, restype, argtypes)
+_i64 = C.c_int64
+_vp = C.c_void_p
+_dp = C.POINTER(C.c_double)
+SYMBOLS = (
+    ("vps_create", C.c_int, (C.POINTER(_vp), C.c_int)),
+    ("vps_destroy", C.c_int, (_vp,)),
+    ("vps_last_error", C.c_char_p, (_vp,)),
+    ("vps_set_stream", C.c_int, (_vp, _vp)),
+    ("vps_sync", C.c_int, (_vp,)),
+    ("vps_version", C.c_int, ()),
+    ("vps_device_info", C.c_int, (_vp, C.POINTER(_i64))),
+    ("vps_malloc", C.c_int, (_vp, C.POINTER(_vp), C.c_size_t)),
+    ("vps_free", C.c_int, (_vp, _vp)),
+    ("vps_memset", C.c_int, (_vp, _vp, C.c_int, C.c_size_t)),
+    ("vps_memcpy_h2d", C.c_int, (_vp, _vp, _vp, C.c_size_t)),
+    ("vps_memcpy_d2h", C.c_int, (_vp, _vp, _vp, C.c_size_t)),
+    ("vps_timing_enable", C.c_int, (_vp, C.c_int)),
+    ("vps_timing_reset", C.c_int, (_vp,)),
+    ("vps_timing_get", C.c_int, (_vp, C.c_int, C.POINTER(_i64), _dp)),
+    ("vps_cell_index", C.c_int, (_vp, _vp, C.c_int, _i64, C.c_int, C.c_double, _vp)),
+    ("vps_deposit_ngp", C.c_int, (_vp, _vp, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_double,
+                                  C.c_int, C.c_int, _vp)),
+    ("vps_density_velocity_vector", C.c_int, (_vp, _vp, _vp, _i64, _vp)),
+    ("vps_nn_workspace_bytes", C.c_size_t, (_i64, C.c_int)),
+    ("vps_nn_resample", C.c_int, (_vp, _vp, C.c_int, _vp, _i64, C.c_int, _dp, C.c_int, _dp, C.c_int,
+                                  _dp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp)),
+    ("vps_field_algebra", C.c_int, (_vp, C.c_int, C.c_int, C.c_double, _vp, _i64)),
+    ("vps_fft_supported", C.c_int, (C.c_int,)),
+    ("vps_set_binning", C.c_int, (_vp, C.c_int, _dp, _dp, C.c_int, C.c_double, C.c_double)),
+    ("vps_fft_workspace_bytes", C.c_size_t, (C.c_int, C.c_int)),
+    ("vps_fft_zy", C.c_int, (_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp)),
+    ("vps_fft_x", C.c_int, (_vp, C.c_int, _i64, _i64, C.c_int, _vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp)),
+    ("vps_power_workspace_bytes", C.c_size_t, (C.c_int,)),
+    ("vps_power_bin", C.c_int, (_vp, C.c_int, _vp, _vp, _vp, _vp)),
+    ("vps_rfft3", C.c_int, (_vp, C.c_int, _vp, _vp, _vp)),
+    ("vps_power_grid", C.c_int, (_vp, C.c_int, _vp, _vp, _vp)),
+    ("vps_pair_k", C.c_int, (_vp, C.c_int, _dp, _dp, _dp, _vp)),
+    ("vps_hist_pairs", C.c_int, (_vp, _vp, _vp, _i64, _dp, C.c_int, _vp, _vp)),
+)
+
+K_DEPOSIT, K_ALGEBRA, K_FFT_Z, K_FFT_Y, K_FFT_X, K_NN_BUILD, K_NN_QUERY, K_MISC = range(8)
+KERNEL_KINDS = {"deposit": K_DEPOSIT, "algebra": K_ALGEBRA, "fft_z": K_FFT_Z, "fft_y": K_FFT_Y,
+                "fft_x": K_FFT_X, "nn_build": K_NN_BUILD, "nn_query": K_NN_QUERY, "misc": K_MISC}
+
+
+class VpsError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into vpower/libvps_hip.so (in tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "vps_internal.h"), os.path.join(REPO_ROOT, "include", "vps_hip.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs, procs = [], []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s).replace(".hip", ".o"))
+        objs.append(o)
+        if not force and os.path.exists(o) and os.path.getmtime(o) >= max(
+                os.path.getmtime(s), os.path.getmtime(deps[-1]), os.path.getmtime(deps[-2])):
+            continue
+        cmd = [hipcc, *HIPCC_FLAGS, "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise VpsError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise VpsError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode(errors="replace")))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library with typed entry points; raises VpsError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VpsError(
+            "libvps_hip.so is not built (%s). Build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    try:
+        handle = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise VpsError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, res, args in SYMBOLS:
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise VpsError("libvps_hip.so lacks symbol %s" % name) from e
+        fn.restype = res
+        fn.argtypes = list(args)
+    _lib = handle
+    return _lib
+
+
+def as_dp(arr):
+    return arr.ctypes.data_as(_dp)
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,459 @@
+"""Device pipeline: particles -> slab grid -> 3-D R2C FFT -> |f|^2 -> shell bins.
+
+Host-side orchestration only.  All arithmetic on grids and particles is done by the
+HIP kernels of libvps_hip.so through `HipKernels`; torch supplies device buffers,
+streams and (for more than one GPU) `torch.distributed` collectives.
+
+Multi-GPU: 1-D slab decomposition along x, one process per GPU.  Particles are
+replicated (as the reference replicates the snapshot on every MPI rank,
+scripts/parallel_optimized.py:272-276); each rank deposits / resamples its own x-slab,
+runs the z and y passes locally, exchanges the half spectrum with ONE all-to-all per
+scalar field (plus a small one for the Nyquist plane), runs the x pass with fused
+binning on its kz-slab and finally all-reduces the (nbins,) shell sums -- the step that
+replaces the two comm.Reduce calls at scripts/parallel_optimized.py:455-456.
+
+The kernel set is injectable so that the distributed choreography can be exercised on
+CPU tensors by the test-suite's oracle-backed stand-in; the product default is
+`HipKernels` and there is no fallback from it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+VELOCITY, MOMENTUM, ENERGY, VM = 0, 1, 2, 3
+QUANTITY = {"velocity": VELOCITY, "momentum": MOMENTUM, "energy": ENERGY}
+FLAG_REFERENCE_MOMENTUM_BUG = 1
+FLAG_INPUT_IS_VM = 2
+
+
+# --------------------------------------------------------------------------- #
+# host-side tables for the binning kernel
+# --------------------------------------------------------------------------- #
+def k_axis(Lbox, Nsize):
+    """2*pi*fftfreq(N, Lcell), as interp.py:1448-1449 / parallel_optimized.py:153-154."""
+    Lcell = Lbox / float(Nsize)
+    return 2 * np.pi * np.fft.fftfreq(Nsize, Lcell)
+
+
+def bin_edges(kmin, kmax, spacing, flavour="library"):
+    """Bin centres and edges with the reference's own numpy expressions:
+    library -> np.arange (interp.py:1472-1473); script -> np.linspace with
+    n_bins=int((kmax-kmin)/spacing)+1 (parallel_optimized.py:178-180)."""
+    if flavour == "library":
+        centers = np.arange(kmin, kmax + spacing, spacing)
+        edges = np.arange(kmin - spacing / 2, kmax + 3 * spacing / 2, spacing)
+    elif flavour == "script":
+        n_bins = int((kmax - kmin) / spacing) + 1
+        centers = np.linspace(kmin, kmax, n_bins)
+        edges = np.linspace(kmin - spacing / 2, kmax + spacing / 2, n_bins + 1)
+    else:
+        raise Exception("flavour must be 'library' or 'script'")
+    if len(edges) != len(centers) + 1:
+        raise Exception("bin centres and edges are inconsistent (%d, %d)" % (len(centers), len(edges)))
+    return centers, edges
+
+
+def sqrt_thresholds(edges):
+    """thr[i] = smallest float64 t with sqrt(t) >= edges[i] (i < nbins) and
+    thr[nbins] = smallest t with sqrt(t) > edges[nbins], so that comparing
+    s = kx^2+ky^2+kz^2 against thr reproduces numpy.histogram's comparison of
+    sqrt(s) against the edges (left-closed bins, last bin right-closed) bit for bit
+    without a square root on the device."""
+    e = np.asarray(edges, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        t = e * e
+        t[e <= 0] = 0.0
+        pos = e > 0
+        lo = t.copy()
+        # lower thresholds: walk down while the predecessor still satisfies sqrt >= e
+        for _ in range(8):
+            prev = np.nextafter(lo, -np.inf)
+            ok = pos & (prev >= 0) & (np.sqrt(np.maximum(prev, 0)) >= e)
+            if not ok.any():
+                break
+            lo = np.where(ok, prev, lo)
+        for _ in range(8):
+            bad = pos & (np.sqrt(lo) < e)
+            if not bad.any():
+                break
+            lo = np.where(bad, np.nextafter(lo, np.inf), lo)
+        # last edge: first t with sqrt(t) > e
+        hi = lo[-1]
+        while np.sqrt(hi) <= e[-1]:
+            hi = np.nextafter(hi, np.inf)
+        while hi > 0 and np.sqrt(np.nextafter(hi, -np.inf)) > e[-1]:
+            hi = np.nextafter(hi, -np.inf)
+    thr = lo.copy()
+    thr[-1] = hi
+    return thr
+
+
+# --------------------------------------------------------------------------- #
+# kernel set backed by libvps_hip.so
+# --------------------------------------------------------------------------- #
+class HipKernels:
+    """Thin typed wrapper of the C ABI working on torch CUDA tensors."""
+
+    name = "hip"
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise _ffi.VpsError("no HIP device is visible to this process; the vpower device path "
+                                "needs an MI355X (there is no CPU fallback)")
+        self.lib = _ffi.lib()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else device.index)
+        h = C.c_void_p()
+        rc = self.lib.vps_create(C.byref(h), self.device.index)
+        if rc != 0:
+            raise _ffi.VpsError("vps_create failed (%d): %s" % (rc, self.lib.vps_last_error(None).decode()))
+        self.ctx = h
+        self._work = {}
+        info = (C.c_int64 * 4)()
+        self._chk(self.lib.vps_device_info(self.ctx, info))
+        self.num_cu, self.lds_per_cu, self.wave, self.hbm_mib = (int(x) for x in info)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.vps_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing -------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise _ffi.VpsError("libvps_hip call failed (%d): %s" % (rc, self.lib.vps_last_error(self.ctx).decode()))
+
+    def _stream(self):
+        self._chk(self.lib.vps_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def _ptr(self, t, dtype=None):
+        if t is None:
+            return None
+        if not t.is_cuda or t.device != self.device:
+            raise _ffi.VpsError("tensor must live on %s (got %s)" % (self.device, t.device))
+        if not t.is_contiguous():
+            raise _ffi.VpsError("tensor must be contiguous")
+        if dtype is not None and t.dtype != dtype:
+            raise _ffi.VpsError("tensor must be %s (got %s)" % (dtype, t.dtype))
+        return C.c_void_p(t.data_ptr())
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def to_device(self, arr, dtype=None):
+        t = torch.as_tensor(np.ascontiguousarray(arr))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device)
+
+    def workspace(self, key, nbytes):
+        w = self._work.get(key)
+        if w is None or w.numel() < nbytes:
+            self._work[key] = None
+            w = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self._work[key] = w
+        return w
+
+    def sync(self):
+        self._chk(self.lib.vps_sync(self.ctx))
+
+    # -- timing ---------------------------------------------------------------
+    def timing(self, on):
+        self._chk(self.lib.vps_timing_enable(self.ctx, 1 if on else 0))
+        self._chk(self.lib.vps_timing_reset(self.ctx))
+
+    def timing_get(self):
+        out = {}
+        for name, kind in _ffi.KERNEL_KINDS.items():
+            n, ms = C.c_int64(), C.c_double()
+            self._chk(self.lib.vps_timing_get(self.ctx, kind, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out
+
+    # -- stage A --------------------------------------------------------------
+    @staticmethod
+    def _pos_kind(pos):
+        if pos.dtype == torch.float32:
+            return 0
+        if pos.dtype == torch.float64:
+            return 1
+        raise _ffi.VpsError("positions must be float32 or float64")
+
+    def cell_index(self, pos, N, Lbox):
+        self._stream()
+        out = self.empty((pos.shape[0], 3), torch.int32)
+        self._chk(self.lib.vps_cell_index(self.ctx, self._ptr(pos), self._pos_kind(pos), pos.shape[0], N,
+                                          float(Lbox), self._ptr(out)))
+        return out
+
+    def density_velocity_vector(self, vel, rho):
+        self._stream()
+        out = self.empty((vel.shape[0], 4), torch.float32)
+        self._chk(self.lib.vps_density_velocity_vector(self.ctx, self._ptr(vel, torch.float32),
+                                                       self._ptr(rho, torch.float32), vel.shape[0],
+                                                       self._ptr(out)))
+        return out
+
+    def deposit(self, pos, payload, N, Lbox, x0, nx, out=None):
+        """payload [np, C] float32 -> grid [C, nx, N, N] float32 (zeroed here unless given)."""
+        self._stream()
+        C_ = payload.shape[1]
+        if out is None:
+            out = self.zeros((C_, nx, N, N), torch.float32)
+        self._chk(self.lib.vps_deposit_ngp(self.ctx, self._ptr(pos), self._pos_kind(pos),
+                                           self._ptr(payload, torch.float32), pos.shape[0], C_, N,
+                                           float(Lbox), x0, nx, self._ptr(out, torch.float32)))
+        return out
+
+    def nn_resample(self, pos, payload, axes, x0, nx, want_index=False, out=None):
+        """Exact NN of every lattice point axes[0][x0:x0+nx] x axes[1] x axes[2]."""
+        self._stream()
+        ax = [np.ascontiguousarray(a, dtype=np.float64) for a in axes]
+        C_ = payload.shape[1]
+        if out is None:
+            out = self.empty((C_, nx, len(ax[1]), len(ax[2])), torch.float32)
+        idx = self.empty((nx, len(ax[1]), len(ax[2])), torch.int32) if want_index else None
+        kind = self._pos_kind(pos)
+        work = self.workspace("nn", self.lib.vps_nn_workspace_bytes(pos.shape[0], kind))
+        self._chk(self.lib.vps_nn_resample(self.ctx, self._ptr(pos), kind, self._ptr(payload, torch.float32),
+                                           pos.shape[0], C_, _ffi.as_dp(ax[0]), len(ax[0]),
+                                           _ffi.as_dp(ax[1]), len(ax[1]), _ffi.as_dp(ax[2]), len(ax[2]),
+                                           x0, nx, self._ptr(out), self._ptr(idx), self._ptr(work)))
+        return out, idx
+
+    def field_algebra(self, chans, quantity, flags, Lcell):
+        self._stream()
+        ncell = chans[0].numel()
+        self._chk(self.lib.vps_field_algebra(self.ctx, quantity, flags, float(Lcell),
+                                             self._ptr(chans, torch.float32), ncell))
+
+    # -- stage B + C ------------------------------------------------------------
+    def fft_supported(self, N):
+        return bool(self.lib.vps_fft_supported(int(N)))
+
+    def set_binning(self, N, k2, thr, edge0, inv_spacing):
+        k2 = np.ascontiguousarray(k2, dtype=np.float64)
+        thr = np.ascontiguousarray(thr, dtype=np.float64)
+        self._stream()
+        self._chk(self.lib.vps_set_binning(self.ctx, N, _ffi.as_dp(k2), _ffi.as_dp(thr), len(thr) - 1,
+                                           float(edge0), float(inv_spacing)))
+
+    def fft_zy(self, field, N, nx, spec=None, nyq=None):
+        """field [nx,N,N] float32 -> spec [N/2,N,nx], nyq [N,nx] (complex64)."""
+        self._stream()
+        if spec is None:
+            spec = self.empty((N // 2, N, nx), torch.complex64)
+        if nyq is None:
+            nyq = self.empty((N, nx), torch.complex64)
+        work = self.workspace("fft", self.lib.vps_fft_workspace_bytes(N, nx))
+        self._chk(self.lib.vps_fft_zy(self.ctx, N, nx, self._ptr(field, torch.float32), self._ptr(spec),
+                                      self._ptr(nyq), self._ptr(work)))
+        return spec, nyq
+
+    def fft_x_bin(self, lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample):
+        self._stream()
+        self._chk(self.lib.vps_fft_x(self.ctx, N, nlines, line0, kz0, self._ptr(lines, torch.complex64), nseg,
+                                     seg_stride, 0, self._ptr(psum, torch.float64),
+                                     self._ptr(nsample, torch.int64), None))
+
+    def fft_x_write(self, lines, N, nlines, nseg, seg_stride, out):
+        self._stream()
+        self._chk(self.lib.vps_fft_x(self.ctx, N, nlines, 0, 0, self._ptr(lines, torch.complex64), nseg,
+                                     seg_stride, 1, None, None, self._ptr(out, torch.complex64)))
+
+    def rfft3(self, field, N):
+        """Half spectrum F[kz][ky][kx], kz <= N/2, of a full [N,N,N] float32 field."""
+        self._stream()
+        out = self.empty((N // 2 + 1, N, N), torch.complex64)
+        work = self.workspace("power", self.lib.vps_power_workspace_bytes(N))
+        self._chk(self.lib.vps_rfft3(self.ctx, N, self._ptr(field, torch.float32), self._ptr(work),
+                                     self._ptr(out)))
+        return out
+
+    def power_grid(self, fields, N):
+        """sum over fields of |F[kz][ky][kx]|^2, kz <= N/2, float32."""
+        self._stream()
+        out = self.zeros((N // 2 + 1, N, N), torch.float32)
+        work = self.workspace("power", self.lib.vps_power_workspace_bytes(N))
+        for f in fields:
+            self._chk(self.lib.vps_power_grid(self.ctx, N, self._ptr(f, torch.float32), self._ptr(work),
+                                              self._ptr(out)))
+        return out
+
+    def pair_k(self, kx, ky, kz):
+        self._stream()
+        ax = [np.ascontiguousarray(a, dtype=np.float64) for a in (kx, ky, kz)]
+        N = len(ax[0])
+        out = self.empty((N * N * N,), torch.float64)
+        self._chk(self.lib.vps_pair_k(self.ctx, N, _ffi.as_dp(ax[0]), _ffi.as_dp(ax[1]), _ffi.as_dp(ax[2]),
+                                      self._ptr(out)))
+        return out
+
+    def hist_pairs(self, k, w, edges):
+        self._stream()
+        edges = np.ascontiguousarray(edges, dtype=np.float64)
+        nb = len(edges) - 1
+        psum = self.zeros((nb,), torch.float64)
+        ns = self.zeros((nb,), torch.int64)
+        self._chk(self.lib.vps_hist_pairs(self.ctx, self._ptr(k, torch.float64),
+                                          self._ptr(w, torch.float64) if w is not None else None,
+                                          k.numel(), _ffi.as_dp(edges), nb, self._ptr(psum), self._ptr(ns)))
+        return psum, ns
+
+
+_default_kernels = {}
+
+
+def default_kernels(device=None):
+    """Process-wide HipKernels for a device (created on first use)."""
+    if device is None:
+        if not torch.cuda.is_available():
+            raise _ffi.VpsError("no HIP device is visible to this process; the vpower device path "
+                                "needs an MI355X (there is no CPU fallback)")
+        device = torch.cuda.current_device()
+    idx = device if isinstance(device, int) else torch.device(device).index
+    k = _default_kernels.get(idx)
+    if k is None:
+        k = HipKernels(idx)
+        _default_kernels[idx] = k
+    return k
+
+
+# --------------------------------------------------------------------------- #
+# the pipeline
+# --------------------------------------------------------------------------- #
+class SlabComm:
+    """Rank / world bookkeeping and the two collectives the path needs."""
+
+    def __init__(self, group=None, enabled=None):
+        import torch.distributed as dist
+        self.dist = dist
+        if enabled is None:
+            enabled = dist.is_available() and dist.is_initialized()
+        self.enabled = bool(enabled)
+        self.group = group
+        self.rank = dist.get_rank(group) if self.enabled else 0
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.backend = dist.get_backend(group) if self.enabled else None
+
+    def all_to_all(self, send):
+        """Equal-split all-to-all along dim 0 of a contiguous tensor."""
+        if self.world == 1:
+            return send
+        if send.is_cuda and self.backend != "nccl":
+            # gloo rehearsal on a GPU box: stage through host memory
+            h = send.cpu()
+            r = torch.empty_like(h)
+            self.dist.all_to_all_single(r, h, group=self.group)
+            return r.to(send.device)
+        if send.is_complex() and self.backend != "nccl":
+            s = torch.view_as_real(send).contiguous()
+            r = torch.empty_like(s)
+            self.dist.all_to_all_single(r, s, group=self.group)
+            return torch.view_as_complex(r)
+        recv = torch.empty_like(send)
+        if send.is_complex():
+            self.dist.all_to_all_single(torch.view_as_real(recv), torch.view_as_real(send), group=self.group)
+        else:
+            self.dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
+    def all_reduce_sum(self, t):
+        if self.world == 1:
+            return t
+        if t.is_cuda and self.backend != "nccl":
+            h = t.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+            return t
+        self.dist.all_reduce(t, group=self.group)
+        return t
+
+
+class PowerPipeline:
+    """P(k) of real fields on an N^3 grid of box length Lbox, slab-decomposed over the
+    ranks of `comm` (default: the initialised torch.distributed world, else 1 rank)."""
+
+    def __init__(self, Nsize, Lbox, kernels=None, comm=None, flavour="library",
+                 kmin=None, kmax=None, kres=None):
+        self.N = int(Nsize)
+        self.Lbox = float(Lbox)
+        self.Lcell = self.Lbox / self.N
+        self.k = kernels if kernels is not None else default_kernels()
+        self.comm = comm if comm is not None else SlabComm()
+        G = self.comm.world
+        if not self.k.fft_supported(self.N):
+            raise Exception("Nsize=%d is not supported by the device FFT (powers of two, 16..4096)" % self.N)
+        if self.N % G or (self.N // 2) % G:
+            raise Exception("Nsize/2=%d must be divisible by the number of ranks %d" % (self.N // 2, G))
+        self.nx = self.N // G
+        self.x0 = self.comm.rank * self.nx
+        self.flavour = flavour
+        # defaults of BoxField.spctrm (interp.py:565-570) / main() (parallel_optimized.py:430)
+        self.kmin = 2 * np.pi / self.Lbox if kmin is None else kmin
+        self.kmax = np.pi / self.Lcell if kmax is None else kmax
+        self.kres = self.kmin if kres is None else kres
+        self.centers, self.edges = bin_edges(self.kmin, self.kmax, self.kres, flavour)
+        self.nbins = len(self.centers)
+        ks = k_axis(self.Lbox, self.N)
+        self.k2 = ks * ks
+        self.thr = sqrt_thresholds(self.edges)
+        spacing = (self.edges[-1] - self.edges[0]) / self.nbins
+        self._binning = (self.N, self.k2, self.thr, float(self.edges[0]), 1.0 / spacing)
+        self.const = (self.Lbox / (2 * np.pi)) ** 1.5 / self.N ** 3   # interp.py:1381
+
+    # -- stage B + C on one or more real fields of this rank's slab ---------------
+    def accumulate(self, fields, psum=None, nsample=None):
+        """Add sum_w |F|^2 of every field ([nx,N,N] float32) into the shell accumulators.
+        Returns LOCAL (this rank's) accumulators; call `finish` to reduce them."""
+        N, nx, G, r = self.N, self.nx, self.comm.world, self.comm.rank
+        k = self.k
+        k.set_binning(*self._binning)
+        if psum is None:
+            psum = k.zeros((self.nbins,), torch.float64)
+            nsample = k.zeros((self.nbins,), torch.int64)
+        nkz = N // 2 // G      # kz rows per rank after the exchange
+        nky = N // G           # Nyquist-plane ky rows per rank
+        for f in fields:
+            spec, nyq = k.fft_zy(f, N, nx)
+            spec = self.comm.all_to_all(spec)
+            nyq = self.comm.all_to_all(nyq)
+            k.fft_x_bin(spec, N, nkz * N, 0, r * nkz, G, nkz * N * nx, psum, nsample)
+            k.fft_x_bin(nyq, N, nky, r * nky, N // 2, G, nky * nx, psum, nsample)
+        return psum, nsample
+
+    def finish(self, psum, nsample, ncomp_counted):
+        """Reduce over ranks and build the reference's (nbins,4) table
+        [centre, P, Psum, Nsample] (interp.py:1478-1480 / parallel_optimized.py:185-188),
+        before the 4 pi k^2 factor.  `ncomp_counted`: how many fields were accumulated
+        into `nsample` (each field counts every mode once)."""
+        self.comm.all_reduce_sum(psum)
+        self.comm.all_reduce_sum(nsample)
+        ps = psum.cpu().numpy() * (0.5 * self.const ** 2)
+        ns = nsample.cpu().numpy() // max(int(ncomp_counted), 1)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            P = ps / ns
+        if self.flavour == "library":
+            P[ns == 0] = 0                      # interp.py:1479
+        return np.column_stack((self.centers, P, ps, ns.astype(np.float64)))
+
+    def spectrum(self, fields):
+        psum, nsample = self.accumulate(fields)
+        tab = self.finish(psum, nsample, len(fields))
+        tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2   # interp.py:590 / parallel_optimized.py:434
+        return tab

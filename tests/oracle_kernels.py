@@ -1,0 +1,61 @@
+"""CPU stand-in for vpower.device.HipKernels, built on numpy, used ONLY by the tests that
+exercise the host-side slab choreography (all-to-all layout, segment addressing, shell
+reduction) without a GPU.  It implements the kernels' documented contracts
+(include/vps_hip.h) -- it is test infrastructure, never imported by the package."""
+import numpy as np
+import torch
+
+
+class OracleKernels:
+    name = "oracle-cpu"
+
+    def __init__(self):
+        self.binning = None
+
+    def fft_supported(self, N):
+        return N >= 4 and (N & (N - 1)) == 0
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype)
+
+    def to_device(self, arr, dtype=None):
+        t = torch.as_tensor(np.ascontiguousarray(arr))
+        return t.to(dtype) if dtype is not None else t
+
+    def set_binning(self, N, k2, thr, edge0, inv_spacing):
+        self.binning = (N, np.asarray(k2), np.asarray(thr))
+
+    def fft_zy(self, field, N, nx):
+        f = field.numpy().astype(np.float64)
+        assert f.shape == (nx, N, N)
+        F = np.fft.fft(np.fft.rfft(f, axis=2), axis=1)       # [x, ky, kz<=N/2]
+        F = np.ascontiguousarray(F.transpose(2, 1, 0)).astype(np.complex64)   # [kz, ky, x]
+        return torch.from_numpy(F[: N // 2].copy()), torch.from_numpy(F[N // 2].copy())
+
+    def _lines(self, lines, N, nlines, nseg, seg_stride):
+        flat = lines.numpy().reshape(-1)
+        seglen = N // nseg
+        segs = [flat[g * seg_stride: g * seg_stride + nlines * seglen].reshape(nlines, seglen)
+                for g in range(nseg)]
+        return np.concatenate(segs, axis=1)
+
+    def fft_x_bin(self, lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample):
+        Nb, k2, thr = self.binning
+        assert Nb == N
+        L = np.fft.fft(self._lines(lines, N, nlines, nseg, seg_stride).astype(np.complex128), axis=1)
+        pw = (L.real ** 2 + L.imag ** 2)
+        g = line0 + np.arange(nlines)
+        ky, kz = g % N, kz0 + g // N
+        assert kz.max() <= N // 2
+        s = (k2[None, :] + k2[ky][:, None]) + k2[kz][:, None]
+        w = np.where((kz == 0) | (2 * kz == N), 1, 2)[:, None] * np.ones((1, N), dtype=np.int64)
+        b = np.searchsorted(thr, s, side="right") - 1
+        ok = (b >= 0) & (b < len(thr) - 1)
+        nb = len(thr) - 1
+        ps = np.bincount(b[ok], weights=(pw * w)[ok], minlength=nb)
+        ns = np.bincount(b[ok], weights=w[ok], minlength=nb)
+        psum += torch.from_numpy(ps)
+        nsample += torch.from_numpy(np.rint(ns).astype(np.int64))

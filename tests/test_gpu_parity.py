@@ -1,0 +1,348 @@
+"""Parity of the HIP path against the oracle / the reference's golden fixtures.
+Run on an MI355X:  python -m pytest tests -m gpu -x -q
+Every test calls through the C ABI (vpower._ffi -> libvps_hip.so)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, synth
+from oracle import vps_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# Stated floating-point tolerances (DESIGN.md section "Parity"):
+PSUM_RTOL = 2e-5      # shell sums: float32 FFT + float32 grids vs the float64 oracle
+FFT_RTOL = 3e-6       # per-mode spectrum error relative to the rms mode amplitude
+
+
+@pytest.fixture(scope="module")
+def K():
+    from vpower import device
+    return device.default_kernels()
+
+
+# ------------------------------------------------------------------ stage A1 ----
+def _edge_positions(N, L, dtype):
+    rng = np.random.default_rng(42)
+    lc = L / N
+    base = np.concatenate([
+        rng.random(20000) * L,
+        np.arange(0, N + 1) * lc,                                   # exact cell faces
+        np.nextafter(np.arange(0, N + 1) * lc, -np.inf),
+        np.nextafter(np.arange(0, N + 1) * lc, np.inf),
+        rng.random(2000) * 3 * L - L,                                # outside the box, negative
+        [0.0, -0.0, L, 2 * L, -L, 1e-30, -1e-30, 7.3 * L],
+    ])
+    base = base.astype(dtype)
+    n = (len(base) // 3) * 3
+    return base[:n].reshape(-1, 3)
+
+
+@pytest.mark.parametrize("N,L", [(16, 1.0), (128, 1.0), (512, 1.0), (500, 1.0), (1000, 1.0), (96, 2.5), (2048, 1.0)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cell_index_bit_exact(K, N, L, dtype):
+    pos = _edge_positions(N, L, dtype)
+    got = K.cell_index(K.to_device(pos), N, L).cpu().numpy()
+    ref = orc.cell_index(pos, N, L)
+    assert np.array_equal(got, ref.astype(np.int32))
+
+
+@pytest.mark.parametrize("tag", ["n16", "n32"])
+def test_cell_index_golden(K, tag):
+    g = golden(f"library_{tag}.npz")
+    N, Np, L, seed = int(g["N"]), int(g["Np"]), float(g["L"]), int(g["seed"])
+    pos = synth(seed, Np, L)[0]
+    assert np.array_equal(K.cell_index(K.to_device(pos), N, L).cpu().numpy(), g["cell_f32"])
+    pos64 = pos.astype(np.float64) * 1.000001
+    assert np.array_equal(K.cell_index(K.to_device(pos64), N, L).cpu().numpy(), g["cell_f64"])
+
+
+@pytest.mark.parametrize("C", [1, 3, 4])
+def test_deposit_matches_oracle(K, C):
+    rng = np.random.default_rng(C)
+    N, L, Np = 32, 1.0, 50000
+    pos = (rng.random((Np, 3)) * L).astype(np.float32)
+    f = rng.standard_normal((Np, C)).astype(np.float32)
+    grid = K.deposit(K.to_device(pos), K.to_device(f), N, L, 0, N).cpu().numpy()     # [C,N,N,N]
+    ref = orc.deposit_to_grid(f.astype(np.float64), pos, N, L)                       # [N,N,N,C]
+    assert np.allclose(grid.transpose(1, 2, 3, 0), ref, rtol=1e-5, atol=1e-5)
+    # slabs tile the full grid
+    parts = [K.deposit(K.to_device(pos), K.to_device(f), N, L, x0, 8).cpu().numpy() for x0 in range(0, N, 8)]
+    assert np.allclose(np.concatenate(parts, axis=1), grid, rtol=1e-5, atol=1e-5)
+
+
+def test_deposit_api_and_integer_conservation():
+    from vpower import interp
+    rng = np.random.default_rng(9)
+    N, L, Np = 64, 1.0, 200000
+    pos = rng.random((Np, 3)) * L                 # float64 positions
+    f = rng.integers(1, 5, Np).astype(np.float64)  # small integers: float32 sums are exact
+    grid = interp.deposit_to_grid(f, pos, N, L)
+    ref = orc.deposit_to_grid(f, pos, N, L)
+    assert grid.dtype == np.float64 and grid.shape == (N, N, N)
+    assert np.array_equal(grid, ref)               # bit exact in the integer regime
+    f5 = rng.integers(0, 3, (Np, 5)).astype(np.float64)   # 5 channels: split 4+1 internally
+    assert np.array_equal(interp.deposit_to_grid(f5, pos, N, L), orc.deposit_to_grid(f5, pos, N, L))
+    # empty input
+    assert np.all(interp.deposit_to_grid(np.zeros(0), np.zeros((0, 3)), N, L) == 0)
+
+
+# ------------------------------------------------------------------ stage A2 ----
+@pytest.mark.parametrize("tag", ["n16", "n32"])
+def test_nn_index_golden_library_lattice(tag):
+    from vpower import interp
+    g = golden(f"library_{tag}.npz")
+    N, Np, L, seed = int(g["N"]), int(g["Np"]), float(g["L"]), int(g["seed"])
+    pos = synth(seed, Np, L)[0].astype(np.float64)
+    ax = orc.lattice_axes_library(L, N)
+    idx = interp.nn_index(pos, (ax, ax, ax))
+    assert np.array_equal(idx.ravel(), g["nn_idx"])
+
+
+@pytest.mark.parametrize("Np,N,dtype", [(1, 8, np.float32), (7, 16, np.float64), (3000, 24, np.float32),
+                                        (200000, 40, np.float32), (200000, 33, np.float64)])
+def test_nn_index_matches_oracle(Np, N, dtype):
+    from vpower import interp
+    rng = np.random.default_rng(Np + N)
+    pos = rng.random((Np, 3)).astype(dtype)
+    pos[: Np // 10] *= 0.05                        # a dense clump: uneven cell occupancy
+    ax = np.linspace(-0.1, 1.1, N)                 # queries outside the particle box too
+    ay = np.linspace(0.0, 1.0, N)
+    az = (np.arange(N) / N).astype(np.float32).astype(np.float64)
+    idx = interp.nn_index(pos, (ax, ay, az))
+    ref = orc.exact_nn_lattice(pos, ax, ay, az)
+    assert np.array_equal(idx.ravel(), ref)
+
+
+def test_nn_ties_lowest_index_and_duplicates():
+    from vpower import interp
+    pos = np.array([[0.25, 0.5, 0.5], [0.75, 0.5, 0.5], [0.75, 0.5, 0.5], [0.25, 0.5, 0.5]], dtype=np.float64)
+    ax = np.array([0.5, 0.2, 0.8])
+    idx = interp.nn_index(pos, (ax, np.array([0.5]), np.array([0.5])))
+    assert idx.ravel().tolist() == [0, 0, 1]       # equidistant -> lowest index; duplicates -> lowest
+
+
+def test_ann_interpolate_api():
+    from vpower import interp
+    rng = np.random.default_rng(2)
+    N, Np = 12, 5000
+    pos = rng.random((Np, 3))
+    q = interp.make_grid_coords(1.0, N)
+    f4 = rng.standard_normal((Np, 4))
+    out = interp.ann_interpolate(pos, q, f4, N, 0.0)
+    ax = orc.lattice_axes_library(1.0, N)
+    ref, idx = orc.ann_interpolate(pos, (ax, ax, ax), f4, N)
+    assert out.shape == (N, N, N, 4) and np.array_equal(out, ref)     # float64 payload: exact gather
+    f1 = rng.standard_normal(Np).astype(np.float32)
+    assert np.array_equal(interp.ann_interpolate(pos, q, f1, N, 0.0), f1[idx].reshape(N, N, N))
+    with pytest.raises(Exception):
+        interp.ann_interpolate(pos, q, f4, N, 0.1)
+    with pytest.raises(Exception):
+        interp.ann_interpolate(pos, q, np.zeros((Np, 2, 2)), N, 0.0)
+
+
+# ------------------------------------------------------------------ stage B ----
+@pytest.mark.parametrize("N", [16, 32, 64, 128, 256])
+def test_rfft3_matches_numpy(K, N):
+    rng = np.random.default_rng(N)
+    f = rng.standard_normal((N, N, N)).astype(np.float32)
+    got = K.rfft3(K.to_device(f), N).cpu().numpy()                  # [kz,ky,kx]
+    ref = np.fft.rfftn(f.astype(np.float64)).transpose(2, 1, 0)     # [kz<=N/2, ky, kx]
+    scale = np.sqrt(np.mean(np.abs(ref) ** 2))
+    assert np.max(np.abs(got - ref)) / scale < FFT_RTOL
+
+
+def test_rfft3_plane_wave_known_answer(K):
+    N = 64
+    x = np.arange(N)
+    f = np.cos(2 * np.pi * (3 * x[:, None, None] + 5 * x[None, :, None] + 7 * x[None, None, :]) / N).astype(np.float32)
+    got = K.rfft3(K.to_device(f), N).cpu().numpy()
+    mag = np.abs(got)
+    assert abs(mag[7, 5, 3] - N ** 3 / 2) < 1e-3 * N ** 3
+    mag[7, 5, 3] = 0
+    assert mag.max() < 1e-3 * N ** 3 / 2
+
+
+@pytest.mark.parametrize("N", [16, 64])
+def test_vector_and_scalar_power_api(N):
+    from vpower import interp
+    rng = np.random.default_rng(7)
+    L = 3.0
+    fx, fy, fz = (rng.standard_normal((N, N, N)) for _ in range(3))
+    P = interp._vector_power(fx, fy, fz, L, N)
+    ref = orc.vector_power(fx, fy, fz, L, N)
+    assert P.shape == (N, N, N) and np.allclose(P, ref, rtol=2e-4, atol=1e-5 * ref.mean())
+    Ps = interp._scalar_power(fx, L, N)
+    assert np.allclose(Ps, orc.scalar_power(fx, L, N), rtol=2e-4, atol=1e-5 * ref.mean())
+    # Parseval normalisation stated at interp.py:1377-1378
+    assert abs(np.sum(P) * (2 * np.pi / L) ** 3 - 0.5 * np.mean(fx ** 2 + fy ** 2 + fz ** 2)) < 1e-5
+    if N == 16:
+        g = golden("fft_power.npz")
+        r = np.random.default_rng(int(g["seed"]))
+        gx, gy, gz = (r.standard_normal((N, N, N)) for _ in range(3))
+        assert np.allclose(interp._vector_power(gx, gy, gz, L, N), g["vector"], rtol=2e-4, atol=1e-5 * g["vector"].mean())
+
+
+# ------------------------------------------------------------------ stage C ----
+@pytest.mark.parametrize("N,L,flavour", [(16, 1.0, "library"), (32, 2.5, "library"), (64, 1.0, "script"),
+                                         (128, 1.0, "library"), (256, 1.0, "script")])
+def test_fused_binning_matches_oracle(K, N, L, flavour):
+    from vpower import device
+    rng = np.random.default_rng(N)
+    fields = [rng.standard_normal((N, N, N)).astype(np.float32) for _ in range(3)]
+    pipe = device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False), flavour=flavour)
+    tab = pipe.spectrum([K.to_device(f) for f in fields])
+    ref = orc.spectrum_table(orc.vector_power(*[f.astype(np.float64) for f in fields], L, N), L, N, flavour)
+    assert np.array_equal(tab[:, 0], ref[:, 0])
+    assert np.array_equal(tab[:, 3], ref[:, 3])                       # Nsample: bit exact
+    assert np.allclose(tab[:, 2], ref[:, 2], rtol=PSUM_RTOL)
+    ok = ref[:, 3] > 0
+    assert np.allclose(tab[ok, 1], ref[ok, 1], rtol=PSUM_RTOL)
+
+
+@pytest.mark.parametrize("N", [16, 32, 64, 128])
+def test_nsample_golden(K, N):
+    from vpower import device
+    g = golden("nsample.npz")
+    for flavour in ("library", "script"):
+        pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=device.SlabComm(enabled=False), flavour=flavour)
+        psum, ns = pipe.accumulate([K.zeros((N, N, N), torch.float32)])
+        assert np.array_equal(ns.cpu().numpy(), g[f"{flavour}_{N}"])
+
+
+def test_custom_k_range_and_unfused_api():
+    from vpower import interp
+    rng = np.random.default_rng(4)
+    N, L = 32, 1.0
+    v = rng.standard_normal((N, N, N, 3))
+    m = np.exp(rng.standard_normal((N, N, N)))
+    bf = interp.BoxField(v, m, L / N)
+    kmin, kmax, kres = 4 * np.pi / L, 20 * np.pi / L, 3 * np.pi / L
+    s = bf.spctrm("velocity", kmin=kmin, kmax=kmax, kres=kres)
+    ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, L / N, "velocity", kmin=kmin, kmax=kmax, kres=kres)
+    assert np.array_equal(s.k, ref[:, 0]) and np.array_equal(s.Nsample, ref[:, 3])
+    assert np.allclose(s.Psum, ref[:, 2], rtol=PSUM_RTOL)
+    # the reference's two-step API: _pair_power then _hist_sample
+    P = orc.vector_power(v[..., 0], v[..., 1], v[..., 2], L, N)
+    pair = interp._pair_power(P, L, N)
+    assert np.array_equal(pair, orc.pair_power(P, L, N))             # float64 k, bit exact
+    tab = interp._hist_sample(pair, 2 * np.pi / L, np.pi * N / L, 2 * np.pi / L)
+    rt = orc.hist_sample(orc.pair_power(P, L, N), 2 * np.pi / L, np.pi * N / L, 2 * np.pi / L, "library")
+    assert np.array_equal(tab[:, 3], rt[:, 3]) and np.allclose(tab[:, 2], rt[:, 2], rtol=1e-12)
+
+
+# ------------------------------------------------------- whole pipeline, goldens ----
+@pytest.mark.parametrize("tag", ["n16", "n32"])
+def test_library_pipeline_against_reference_golden(tag):
+    from vpower import interp
+    g = golden(f"library_{tag}.npz")
+    N, Np, L, seed = int(g["N"]), int(g["Np"]), float(g["L"]), int(g["seed"])
+    pos, vel, mass, dens = synth(seed, Np, L)
+    gp = interp.GasParticles(pos.astype(np.float64), mass.astype(np.float64), dens.astype(np.float64),
+                             vel.astype(np.float64), L)
+    interp.REFERENCE_COMPAT["momentum_bug"] = True       # the golden tables carry quirk Q1
+    try:
+        for maker, prefix in ((gp.deposit_to_field, "ngp"), (gp.ann_interp_to_field, "nn")):
+            bf = maker(N)
+            assert bf.Nsize == N and abs(bf.Lbox - L) < 1e-12
+            for q in ("velocity", "momentum", "energy"):
+                s = bf.spctrm(q)
+                ref = g[f"{prefix}_{q}"]
+                assert np.array_equal(s.k, ref[:, 0])
+                assert np.array_equal(s.Nsample, ref[:, 3])
+                assert np.allclose(s.Psum, ref[:, 2], rtol=PSUM_RTOL)
+                assert np.allclose(s.P, ref[:, 1], rtol=PSUM_RTOL)
+        assert np.allclose(gp.ann_interp_to_field(N).mass[0, 0, :8], g["nn_mass_head"], rtol=1e-6)
+        grid = interp.deposit_to_grid(gp.density_velocity_vector(), gp.pos, N, L)
+        assert np.allclose(grid, g["deposit_grid"], rtol=1e-5, atol=1e-5)
+    finally:
+        interp.REFERENCE_COMPAT["momentum_bug"] = False
+    # default (physically correct) momentum differs from the quirk
+    s = gp.deposit_to_field(N).spctrm("momentum")
+    assert not np.allclose(s.Psum, g["ngp_momentum"][:, 2], rtol=1e-3)
+    with pytest.raises(Exception):
+        gp.deposit_to_field(N).spctrm("vorticity")
+
+
+def _load_script():
+    path = os.path.join(ROOT, "large-velocity-power-spectrum_amd", "scripts", "parallel_optimized.py")
+    spec = importlib.util.spec_from_file_location("vps_script", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("tag", ["n16", "n32"])
+def test_script_main_against_reference_golden(tmp_path, tag):
+    g = golden(f"script_{tag}.npz")
+    N, Np, L, seed = int(g["N"]), int(g["Np"]), int(g["L"]), int(g["seed"])
+    pos, vel, mass, dens = synth(seed, Np, float(L), lognormal_density=False)
+    snap = tmp_path / "snap.npz"
+    np.savez(snap, Coordinates=pos, Masses=mass, Velocities=vel)
+    s = _load_script()
+    assert s.main(["-i", str(snap), "-o", str(tmp_path), "-N", str(N), "-M", str(N), "-l", str(L), "-f"]) == 0
+    pk = np.loadtxt(tmp_path / "Pk.txt")
+    ref = g["Pk"]
+    assert pk.shape == ref.shape
+    assert np.array_equal(pk[:, 3], ref[:, 3])
+    assert np.allclose(pk[:, 0], ref[:, 0], rtol=1e-7)
+    assert np.allclose(pk[:, 2], ref[:, 2], rtol=PSUM_RTOL)
+    assert np.allclose(pk[:, 1], ref[:, 1], rtol=PSUM_RTOL)
+
+
+def test_config1_full_size_against_oracle():
+    """BASELINE config 1 (128^3, 1e5 particles, velocity P(k), script flavour) end to end."""
+    from vpower import synth as sy
+    s = _load_script()
+    N, Np, off = sy.CONFIGS["C1"]
+    pos, vel, mass, dens = sy.particles(sy.BASE_SEED + off, Np, 1.0, lognormal_density=False, preprocess=False)
+    tab = s.velocity_spectrum(pos, mass, vel, N, 1)
+    c, v = orc.preprocess_script(pos, mass, vel)
+    ref, _ = orc.script_pipeline(c, v, N, 1)
+    assert np.array_equal(tab[:, 3], ref[:, 3])
+    assert np.allclose(tab[:, 2], ref[:, 2], rtol=PSUM_RTOL)
+    assert np.allclose(tab[:, 1], ref[:, 1], rtol=PSUM_RTOL)
+
+
+# -------------------------------------------- full-size properties (config 2) ----
+def test_config2_properties(K):
+    """512^3 / 1e7 particles: properties that need no CPU reference at this size --
+    mass conservation of the deposit, Parseval of FFT+binning, linearity, and the exact
+    number of modes falling inside the binned shell range."""
+    from vpower import device, synth as sy
+    N, Np, off = sy.CONFIGS["C2"]
+    L = 1.0
+    pos, vel, mass, dens = sy.particles(sy.BASE_SEED + off, Np, L)
+    dpos = K.to_device(pos)
+    payload = K.density_velocity_vector(K.to_device(vel), K.to_device(dens))
+    grid = K.deposit(dpos, payload, N, L, 0, N)
+    tot = grid.sum(dim=(1, 2, 3), dtype=torch.float64).cpu().numpy()
+    ref = (vel.astype(np.float64) * dens[:, None]).sum(0)
+    assert np.allclose(tot[:3], ref, rtol=1e-6, atol=1e-3 * np.sqrt(Np))
+    assert abs(tot[3] - dens.astype(np.float64).sum()) < 1e-6 * Np
+    K.field_algebra(grid, device.VELOCITY, 0, L / N)
+    pipe = device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False))
+    fields = [grid[0], grid[1], grid[2]]
+    tab = pipe.finish(*pipe.accumulate(fields), 3)
+    # every mode except k=0 and the corners beyond kmax+kres/2 is counted exactly once
+    ks = device.k_axis(L, N)
+    k2 = ks * ks
+    inside = 0
+    thr = pipe.thr
+    for i in range(N):                       # exact count, one x-plane at a time
+        s = (k2[i] + k2[:, None]) + k2[None, :]
+        inside += int(np.count_nonzero((s >= thr[0]) & (s < thr[-1])))
+    assert int(tab[:, 3].sum()) == inside
+    # Parseval over the binned range: sum Psum (2pi/L)^3 = 0.5 <|v|^2> minus the excluded modes
+    v2 = sum((f.double() ** 2).sum().item() for f in fields) / N ** 3
+    total = tab[:, 2].sum() * (2 * np.pi / L) ** 3
+    assert 0.5 * v2 * 0.45 < total <= 0.5 * v2 * (1 + 1e-5)      # corners hold < 55% of white noise
+    # linearity: P(2 f) = 4 P(f), bit-for-bit equal Nsample
+    tab2 = pipe.finish(*pipe.accumulate([2 * fields[0]]), 1)
+    tab1 = pipe.finish(*pipe.accumulate([fields[0]]), 1)
+    assert np.array_equal(tab1[:, 3], tab2[:, 3])
+    assert np.allclose(tab2[:, 2], 4 * tab1[:, 2], rtol=1e-6)
