@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path particles -> P(k) on MI355X, one process per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W] [--config C2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the path over one synthetic particle set already resident in
+HBM: zero the slab grid, rho*v payload, NGP deposit (4 channels), v = rho v / rho, three
+z/y FFT passes + all-to-all (N>1) + x pass with fused |F|^2 shell binning, shell all-reduce,
+download of the (nbins,) sums, P(k) table.  Workload: BASELINE.json configs[1]
+(512^3 grid, 1e7 particles, velocity P(k), nearest-grid-point deposition); with N>1 the SAME
+grid is slab-decomposed over the N GPUs (strong scaling, one RCCL all-to-all per field).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "large-velocity-power-spectrum_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(sample_N=256, density=10_000_000 / 512 ** 3):
+    """The oracle (numpy restatement of the reference, kind 'port') timed on this host on a
+    bounded sample of the same workload: same particle density, grid 256^3 instead of 512^3
+    (1/8 of the cells and particles), one core (the reference pins FFTW to threads=1,
+    vpower/interp.py:1382)."""
+    from oracle import vps_oracle as orc
+    from vpower import synth
+    Np = int(round(density * sample_N ** 3))
+    pos, vel, mass, dens = synth.particles(synth.BASE_SEED + 2, Np, 1.0)
+    t0 = time.perf_counter()
+    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
+    grid = orc.deposit_to_grid_fast(vec, pos, sample_N, 1.0)
+    v, m = orc.vm_from_vec_grid(grid, 1.0 / sample_N, zero_empty=True)
+    t1 = time.perf_counter()
+    P = orc.vector_power(v[..., 0], v[..., 1], v[..., 2], 1.0, sample_N)
+    t2 = time.perf_counter()
+    orc.spectrum_table(P, 1.0, sample_N, "library")
+    t3 = time.perf_counter()
+    total = t3 - t0
+    return {
+        "value": sample_N ** 3 * 3 / total, "unit": "grid cells*components/s", "cores": 1, "kind": "port",
+        "sample": "oracle/vps_oracle.py on %d^3 cells, %d particles (1/8 of the workload at equal "
+                  "particle density), float64, 1 thread: deposit %.2fs, 3 FFTs+power %.2fs, "
+                  "pair+hist %.2fs" % (sample_N, Np, t1 - t0, t2 - t1, t3 - t2),
+        "seconds": total,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2", help="C1..C5 of vpower.synth.CONFIGS (grid, particles)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5, help="extra instrumented steps for the roofline")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from vpower import device, synth
+    K = device.default_kernels(local)
+    N, Np, off = synth.CONFIGS[args.config]
+    L = 1.0
+    comm = device.SlabComm()
+    pipe = device.PowerPipeline(N, L, kernels=K, comm=comm, flavour="library")
+    nx, x0 = pipe.nx, pipe.x0
+
+    # ---- inputs: generated on the host once, resident in HBM before the timed region ----
+    pos, vel, mass, dens = synth.particles(synth.BASE_SEED + off, Np, L)
+    dpos, dvel, drho = K.to_device(pos), K.to_device(vel), K.to_device(dens)
+    del pos, vel, mass, dens
+    grid = K.empty((4, nx, N, N), torch.float32)
+    spec = K.empty((N // 2, N, nx), torch.complex64)
+    nyq = K.empty((N, nx), torch.complex64)
+    psum = K.zeros((pipe.nbins,), torch.float64)
+    nsample = K.zeros((pipe.nbins,), torch.int64)
+    G = world
+    nkz, nky = N // 2 // G, N // G
+
+    def step():
+        grid.zero_()
+        payload = K.density_velocity_vector(dvel, drho)
+        K.deposit(dpos, payload, N, L, x0, nx, out=grid)
+        K.field_algebra(grid, device.VELOCITY, 0, L / N)
+        psum.zero_()
+        nsample.zero_()
+        K.set_binning(*pipe._binning)
+        for c in range(3):
+            s, q = K.fft_zy(grid[c], N, nx, spec=spec, nyq=nyq)
+            s = comm.all_to_all(s)
+            q = comm.all_to_all(q)
+            K.fft_x_bin(s, N, nkz * N, 0, rank * nkz, G, nkz * N * nx, psum, nsample)
+            K.fft_x_bin(q, N, nky, rank * nky, N // 2, G, nky * nx, psum, nsample)
+        tab = pipe.finish(psum, nsample, 3)     # all-reduce, D2H, table
+        tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2
+        return tab
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tab = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tab = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    cells = float(N) ** 3 * 3            # grid cells x components per step (whole job)
+
+    # ---- per-kernel durations (HIP events on the library's stream), untimed extra steps ----
+    K.timing(True)
+    for _ in range(args.profile_steps):
+        step()
+    tim = K.timing_get()
+    per = {k: K.timing_list(k) for k in ("fft_z", "fft_y", "fft_x", "deposit", "algebra")}
+    K.timing(False)
+    nst = args.profile_steps
+    # y and x launches alternate main / Nyquist-plane; the main launch is the big one
+    main_y, main_x = per["fft_y"][0::2], per["fft_x"][0::2]
+    NH = N // 2
+    alg_bytes = {   # algorithmic HBM bytes per main launch (DESIGN.md "Kernels")
+        "fft_z": 4.0 * nx * N * N + 8.0 * nx * N * (NH + 1),
+        "fft_y": 16.0 * nx * N * NH,
+        "fft_x": 8.0 * nkz * N * N,
+        "deposit": 28.0 * Np + 0.0,      # particle reads (grid RMW is data dependent)
+    }
+    avg_ms = {"fft_z": float(np.mean(per["fft_z"])), "fft_y": float(np.mean(main_y)),
+              "fft_x": float(np.mean(main_x)), "deposit": float(np.mean(per["deposit"]))}
+    step_kernel_ms = {k: v[1] / nst for k, v in tim.items() if v[0]}
+    dom = max(("fft_z", "fft_y", "fft_x"), key=lambda k: step_kernel_ms.get(k, 0.0))
+    ach = alg_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
+    fft_ms = sum(step_kernel_ms.get(k, 0.0) for k in ("fft_z", "fft_y", "fft_x"))
+    fft_bytes = 3 * (alg_bytes["fft_z"] + 16.0 * nx * N * (NH + 1) + 8.0 * (nkz * N + nky) * N)
+    traffic = None
+    tr_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tr_path) and args.config == "C2" and world == 1:
+        try:
+            traffic = json.load(open(tr_path)).get(dom)
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "particles gridded/s + 3D FFT cells/s (N^3 x components / step time, whole path "
+                  "particles->P(k)); HBM % of roofline",
+        "value": cells * args.steps / dt,
+        "unit": "grid cells*components/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d^3 grid, %d particles, velocity P(k), NGP deposit, library binning"
+                               % (args.config, N, Np), "grid": N, "particles": Np,
+                   "parallelism": "x-slab x%d, 1 all-to-all/field" % world},
+        "particles_per_s": Np / (avg_ms["deposit"] * 1e-3) if avg_ms["deposit"] > 0 else None,
+        "fft_cells_per_s": cells / (fft_ms * 1e-3) / 1.0 if fft_ms > 0 else None,
+        "fft_stage": {"ms_per_step": fft_ms, "algorithmic_GBs": fft_bytes / (fft_ms * 1e-3) / 1e9 if fft_ms else None,
+                      "frac_of_hbm_peak": fft_bytes / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fft_ms else None},
+        "kernel_ms_per_step": step_kernel_ms,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": avg_ms[dom]},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        assert np.isfinite(tab[:, 2]).all() and tab[:, 3].sum() > 0
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

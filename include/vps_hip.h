@@ -78,6 +78,8 @@ enum vps_kernel_kind {
 int vps_timing_enable(vps_ctx* ctx, int on);
 int vps_timing_reset(vps_ctx* ctx);
 int vps_timing_get(vps_ctx* ctx, int kind, int64_t* launches, double* total_ms);
+/* per-launch durations (ms) of kind `kind` in launch order; *n_out = how many exist */
+int vps_timing_list(vps_ctx* ctx, int kind, double* ms_out, int64_t cap, int64_t* n_out);
 
 /* ---- stage A1: nearest-grid-point deposition ---------------------------- */
 /* Replaces deposit_to_grid (vpower/interp.py:996-1015).

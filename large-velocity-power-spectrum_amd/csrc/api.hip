@@ -183,6 +183,23 @@ int vps_timing_get(vps_ctx* ctx, int kind, int64_t* launches, double* total_ms) 
   return VPS_OK;
 }
 
+int vps_timing_list(vps_ctx* ctx, int kind, double* ms_out, int64_t cap, int64_t* n_out) {
+  if (!ctx || kind < 0 || kind >= VPS_K_COUNT || cap < 0 || (cap && !ms_out)) return VPS_ERR_ARG;
+  VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  int64_t n = 0;
+  for (auto& l : ctx->launches) {
+    if (l.kind != kind) continue;
+    if (n < cap) {
+      float t = 0.f;
+      VPS_HIP_CHECK(ctx, hipEventElapsedTime(&t, l.start, l.stop));
+      ms_out[n] = t;
+    }
+    ++n;
+  }
+  if (n_out) *n_out = n;
+  return VPS_OK;
+}
+
 int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const double* thr_host,
                     int nbins, double edge0, double inv_spacing) {
   if (!ctx) return VPS_ERR_ARG;
@@ -192,6 +209,12 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
   for (int i = 0; i < nbins; ++i)
     if (!(thr_host[i] <= thr_host[i + 1]))
       return vps_fail(ctx, VPS_ERR_ARG, "vps_set_binning: thresholds must be non-decreasing (i=%d)", i);
+  // unchanged tables (the usual case inside a loop over fields/steps): nothing to do
+  if (ctx->d_k2 && ctx->bin_N == N && ctx->nbins == nbins && ctx->edge0 == edge0 &&
+      ctx->inv_spacing == inv_spacing && (int)ctx->h_k2.size() == N &&
+      memcmp(ctx->h_k2.data(), k2_axis_host, sizeof(double) * N) == 0 &&
+      memcmp(ctx->h_thr.data(), thr_host, sizeof(double) * (nbins + 1)) == 0)
+    return VPS_OK;
   // the x pass may still be reading the old tables
   VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->d_k2) VPS_HIP_CHECK(ctx, hipFree(ctx->d_k2));
@@ -201,6 +224,8 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
   VPS_HIP_CHECK(ctx, hipMalloc(&ctx->d_thr, sizeof(double) * (nbins + 1)));
   VPS_HIP_CHECK(ctx, hipMemcpy(ctx->d_k2, k2_axis_host, sizeof(double) * N, hipMemcpyHostToDevice));
   VPS_HIP_CHECK(ctx, hipMemcpy(ctx->d_thr, thr_host, sizeof(double) * (nbins + 1), hipMemcpyHostToDevice));
+  ctx->h_k2.assign(k2_axis_host, k2_axis_host + N);
+  ctx->h_thr.assign(thr_host, thr_host + nbins + 1);
   ctx->bin_N = N;
   ctx->nbins = nbins;
   ctx->edge0 = edge0;

@@ -38,6 +38,7 @@ SYMBOLS = (
     ("vps_timing_enable", C.c_int, (_vp, C.c_int)),
     ("vps_timing_reset", C.c_int, (_vp,)),
     ("vps_timing_get", C.c_int, (_vp, C.c_int, C.POINTER(_i64), _dp)),
+    ("vps_timing_list", C.c_int, (_vp, C.c_int, _dp, _i64, C.POINTER(_i64))),
     ("vps_cell_index", C.c_int, (_vp, _vp, C.c_int, _i64, C.c_int, C.c_double, _vp)),
     ("vps_deposit_ngp", C.c_int, (_vp, _vp, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_double,
                                   C.c_int, C.c_int, _vp)),

@@ -185,6 +185,14 @@ class HipKernels:
             out[name] = (n.value, ms.value)
         return out
 
+    def timing_list(self, name):
+        kind = _ffi.KERNEL_KINDS[name]
+        n = C.c_int64()
+        self._chk(self.lib.vps_timing_list(self.ctx, kind, None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value, 1), dtype=np.float64)
+        self._chk(self.lib.vps_timing_list(self.ctx, kind, _ffi.as_dp(buf), n.value, C.byref(n)))
+        return buf[: n.value]
+
     # -- stage A --------------------------------------------------------------
     @staticmethod
     def _pos_kind(pos):

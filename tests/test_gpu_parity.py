@@ -199,9 +199,9 @@ def test_fused_binning_matches_oracle(K, N, L, flavour):
     ref = orc.spectrum_table(orc.vector_power(*[f.astype(np.float64) for f in fields], L, N), L, N, flavour)
     assert np.array_equal(tab[:, 0], ref[:, 0])
     assert np.array_equal(tab[:, 3], ref[:, 3])                       # Nsample: bit exact
-    assert np.allclose(tab[:, 2], ref[:, 2], rtol=PSUM_RTOL)
+    assert np.allclose(tab[:, 2], ref[:, 2], rtol=PSUM_RTOL, atol=0)
     ok = ref[:, 3] > 0
-    assert np.allclose(tab[ok, 1], ref[ok, 1], rtol=PSUM_RTOL)
+    assert np.allclose(tab[ok, 1], ref[ok, 1], rtol=PSUM_RTOL, atol=0)
 
 
 @pytest.mark.parametrize("N", [16, 32, 64, 128])
@@ -225,7 +225,7 @@ def test_custom_k_range_and_unfused_api():
     s = bf.spctrm("velocity", kmin=kmin, kmax=kmax, kres=kres)
     ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, L / N, "velocity", kmin=kmin, kmax=kmax, kres=kres)
     assert np.array_equal(s.k, ref[:, 0]) and np.array_equal(s.Nsample, ref[:, 3])
-    assert np.allclose(s.Psum, ref[:, 2], rtol=PSUM_RTOL)
+    assert np.allclose(s.Psum, ref[:, 2], rtol=PSUM_RTOL, atol=0)
     # the reference's two-step API: _pair_power then _hist_sample
     P = orc.vector_power(v[..., 0], v[..., 1], v[..., 2], L, N)
     pair = interp._pair_power(P, L, N)
@@ -254,8 +254,8 @@ def test_library_pipeline_against_reference_golden(tag):
                 ref = g[f"{prefix}_{q}"]
                 assert np.array_equal(s.k, ref[:, 0])
                 assert np.array_equal(s.Nsample, ref[:, 3])
-                assert np.allclose(s.Psum, ref[:, 2], rtol=PSUM_RTOL)
-                assert np.allclose(s.P, ref[:, 1], rtol=PSUM_RTOL)
+                assert np.allclose(s.Psum, ref[:, 2], rtol=PSUM_RTOL, atol=0)
+                assert np.allclose(s.P, ref[:, 1], rtol=PSUM_RTOL, atol=0)
         assert np.allclose(gp.ann_interp_to_field(N).mass[0, 0, :8], g["nn_mass_head"], rtol=1e-6)
         grid = interp.deposit_to_grid(gp.density_velocity_vector(), gp.pos, N, L)
         assert np.allclose(grid, g["deposit_grid"], rtol=1e-5, atol=1e-5)
@@ -263,7 +263,7 @@ def test_library_pipeline_against_reference_golden(tag):
         interp.REFERENCE_COMPAT["momentum_bug"] = False
     # default (physically correct) momentum differs from the quirk
     s = gp.deposit_to_field(N).spctrm("momentum")
-    assert not np.allclose(s.Psum, g["ngp_momentum"][:, 2], rtol=1e-3)
+    assert not np.allclose(s.Psum, g["ngp_momentum"][:, 2], rtol=1e-3, atol=0)
     with pytest.raises(Exception):
         gp.deposit_to_field(N).spctrm("vorticity")
 
@@ -290,8 +290,8 @@ def test_script_main_against_reference_golden(tmp_path, tag):
     assert pk.shape == ref.shape
     assert np.array_equal(pk[:, 3], ref[:, 3])
     assert np.allclose(pk[:, 0], ref[:, 0], rtol=1e-7)
-    assert np.allclose(pk[:, 2], ref[:, 2], rtol=PSUM_RTOL)
-    assert np.allclose(pk[:, 1], ref[:, 1], rtol=PSUM_RTOL)
+    assert np.allclose(pk[:, 2], ref[:, 2], rtol=PSUM_RTOL, atol=0)
+    assert np.allclose(pk[:, 1], ref[:, 1], rtol=PSUM_RTOL, atol=0)
 
 
 def test_config1_full_size_against_oracle():
@@ -304,8 +304,8 @@ def test_config1_full_size_against_oracle():
     c, v = orc.preprocess_script(pos, mass, vel)
     ref, _ = orc.script_pipeline(c, v, N, 1)
     assert np.array_equal(tab[:, 3], ref[:, 3])
-    assert np.allclose(tab[:, 2], ref[:, 2], rtol=PSUM_RTOL)
-    assert np.allclose(tab[:, 1], ref[:, 1], rtol=PSUM_RTOL)
+    assert np.allclose(tab[:, 2], ref[:, 2], rtol=PSUM_RTOL, atol=0)
+    assert np.allclose(tab[:, 1], ref[:, 1], rtol=PSUM_RTOL, atol=0)
 
 
 # -------------------------------------------- full-size properties (config 2) ----
