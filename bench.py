@@ -113,9 +113,9 @@ def main():
             s, q = K.fft_zy(grid[c], N, nx, spec=spec, nyq=nyq)
             s = comm.all_to_all(s)
             q = comm.all_to_all(q)
-            K.fft_x_bin(s, N, nkz * N, 0, rank * nkz, G, nkz * N * nx, psum, nsample)
-            K.fft_x_bin(q, N, nky, rank * nky, N // 2, G, nky * nx, psum, nsample)
-        tab = pipe.finish(psum, nsample, 3)     # all-reduce, D2H, table
+            K.fft_x_bin(s, N, nkz * N, 0, rank * nkz, G, nkz * N * nx, psum, nsample, count=(c == 0))
+            K.fft_x_bin(q, N, nky, rank * nky, N // 2, G, nky * nx, psum, nsample, count=(c == 0))
+        tab = pipe.finish(psum, nsample)     # all-reduce, D2H, table
         tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2
         return tab
 

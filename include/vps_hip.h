@@ -162,6 +162,8 @@ int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev,
  *         psum_dev[nbins] (float64) and w into nsample_dev[nbins] (uint64) using
  *         the tables of vps_set_binning;  replaces _pair_power+_hist_sample
  *         (interp.py:1440-1482) / pair_power+hist_sample (parallel_optimized.py:145-190).
+ * mode 3: as mode 0 but shell sums only (nsample_dev untouched): the counts depend on the
+ *         mode lattice alone, so a vector spectrum counts once, on its first component.
  * mode 1: write the transformed lines to out_dev[i][kx] (complex64, contiguous).
  * mode 2: out_dev[i][kx] (float32) += |F|^2, no binning (component sums of
  *         _vector_power, interp.py:1386).                                           */

@@ -364,7 +364,6 @@ struct XParams {
   int nbins;
   float edge0, inv_spacing;
   double* psum;
-  unsigned long long* nsample;
 };
 
 template <int NC, int T, int MODE, bool SEG>
@@ -372,22 +371,21 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   typedef PlanInfo<NC> PI;
   constexpr int L = PI::L, RL = PI::RL, NT = T * L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  // carve: thr (double) | hsum (double) | tw | line buffers | hcnt
+  // carve: thr (double) | hsum (double) | tw | line buffers
   double* thr = reinterpret_cast<double*>(smem_raw);
   double* hsum = thr + (MODE == 0 ? (p.nbins + 1) : 0);
   cf* tw = reinterpret_cast<cf*>(hsum + (MODE == 0 ? p.nbins : 0));
   cf* buf = tw + ((PI::TW + 1) & ~1);
-  unsigned* hcnt = reinterpret_cast<unsigned*>(buf + T * PI::PITCH);
 
   const int tid = threadIdx.x;
   const int t = tid / L, l = tid % L;
   for (int i = tid; i < PI::TW; i += NT) tw[i] = p.tw_stage[i];
+  double k2x[MODE == 0 ? RL : 1];   // fl(kx*kx) of this lane's contiguous chunk of kx
   if constexpr (MODE == 0) {
     for (int i = tid; i <= p.nbins; i += NT) thr[i] = p.thr[i];
-    for (int i = tid; i < p.nbins; i += NT) {
-      hsum[i] = 0.0;
-      hcnt[i] = 0u;
-    }
+    for (int i = tid; i < p.nbins; i += NT) hsum[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < RL; ++i) k2x[i] = p.k2[l * RL + i];
   }
   __syncthreads();
 
@@ -430,44 +428,121 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
         for (int i = 0; i < RL; ++i) o[out_index<NC>(l, i)] += v[i].x * v[i].x + v[i].y * v[i].y;
       }
     } else {
-      // |F|^2 of the line goes through LDS so that the binning loop below is a small
-      // rolled loop over kx instead of RL unrolled copies
+      // Shell sums.  |F|^2 goes through LDS once so that every lane gets a CONTIGUOUS chunk
+      // of RL kx values: along kx the shell index moves monotonically (per half line), so a
+      // lane accumulates each run of equal bins in registers and issues one LDS float64
+      // atomic per run, and the lanes of a wave-instruction hit different bins.
       float* pw = reinterpret_cast<float*>(line);
       if constexpr (PI::R1 > 1) __syncthreads();  // last exchange fully consumed
 #pragma unroll
-      for (int i = 0; i < RL; ++i) pw[out_index<NC>(l, i)] = v[i].x * v[i].x + v[i].y * v[i].y;
+      for (int i = 0; i < RL; ++i) {
+        const int k = out_index<NC>(l, i);
+        pw[k + k / RL] = v[i].x * v[i].x + v[i].y * v[i].y;   // one pad word per chunk
+      }
       __syncthreads();
       if (live) {
         const long long g = p.line0 + li;
         const int ky = (int)(g % p.N);
         const int kz = p.kz0 + (int)(g / p.N);
         const double k2y = p.k2[ky], k2z = p.k2[kz];
-        const unsigned w = (kz == 0 || 2 * kz == p.N) ? 1u : 2u;
-        const double wd = (double)w;
-        for (int kx = l; kx < NC; kx += L) {
+        const double wd = (kz == 0 || 2 * kz == p.N) ? 1.0 : 2.0;
+        const float* mine = pw + l * (RL + 1);
+        int cur = -1;
+        double lo = 1.0, hi = 0.0, acc = 0.0;   // empty interval: first element searches
+#pragma unroll
+        for (int i = 0; i < RL; ++i) {
           // s = (kx*kx + ky*ky) + kz*kz with numpy's rounding (the table holds fl(k*k))
-          const double s = (p.k2[kx] + k2y) + k2z;
-          int bi = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
-          bi = min(max(bi, 0), p.nbins - 1);
-          while (bi > 0 && s < thr[bi]) --bi;
-          while (bi < p.nbins - 1 && s >= thr[bi + 1]) ++bi;
-          if (s >= thr[bi] && s < thr[bi + 1]) {
-            atomicAdd(&hsum[bi], (double)pw[kx] * wd);
-            atomicAdd(&hcnt[bi], w);
+          const double s = (k2x[i] + k2y) + k2z;
+          if (!(s >= lo && s < hi)) {
+            if (cur >= 0) atomicAdd(&hsum[cur], acc * wd);
+            acc = 0.0;
+            int bi = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
+            bi = min(max(bi, 0), p.nbins - 1);
+            while (bi > 0 && s < thr[bi]) --bi;
+            while (bi < p.nbins - 1 && s >= thr[bi + 1]) ++bi;
+            lo = thr[bi];
+            hi = thr[bi + 1];
+            cur = bi;
+            if (s < lo) {          // below the first edge (e.g. the k = 0 mode)
+              cur = -1; hi = lo; lo = -INFINITY;
+            } else if (s >= hi) {  // beyond the last edge (corner modes)
+              cur = -1; lo = hi; hi = INFINITY;
+            }
           }
+          if (cur >= 0) acc += (double)mine[i];
         }
+        if (cur >= 0) atomicAdd(&hsum[cur], acc * wd);
       }
     }
   }
   if constexpr (MODE == 0) {
     __syncthreads();
     for (int i = tid; i < p.nbins; i += NT) {
-      const unsigned c = hcnt[i];
-      if (c) {
-        atomicAdd(&p.psum[i], hsum[i]);
-        atomicAdd(&p.nsample[i], (unsigned long long)c);
-      }
+      const double hs = hsum[i];
+      if (hs != 0.0) atomicAdd(&p.psum[i], hs);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------
+// Shell COUNTS of the same lines (input independent): one thread walks one line and adds
+// each run of equal bins with one LDS atomic.  Same s / threshold arithmetic as above.
+// ------------------------------------------------------------------------------
+struct CountParams {
+  long long nlines, line0;
+  int N, kz0;
+  const double* k2;
+  const double* thr;
+  int nbins;
+  float edge0, inv_spacing;
+  unsigned long long* nsample;
+};
+
+__global__ void __launch_bounds__(256) count_modes_kernel(const CountParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* thr = reinterpret_cast<double*>(smem_raw);
+  double* k2 = thr + p.nbins + 1;
+  unsigned* hcnt = reinterpret_cast<unsigned*>(k2 + p.N);
+  for (int i = threadIdx.x; i <= p.nbins; i += blockDim.x) thr[i] = p.thr[i];
+  for (int i = threadIdx.x; i < p.N; i += blockDim.x) k2[i] = p.k2[i];
+  for (int i = threadIdx.x; i < p.nbins; i += blockDim.x) hcnt[i] = 0u;
+  __syncthreads();
+  for (long long li = (long long)blockIdx.x * blockDim.x + threadIdx.x; li < p.nlines;
+       li += (long long)gridDim.x * blockDim.x) {
+    const long long g = p.line0 + li;
+    const int ky = (int)(g % p.N);
+    const int kz = p.kz0 + (int)(g / p.N);
+    const double k2y = k2[ky], k2z = k2[kz];
+    const unsigned w = (kz == 0 || 2 * kz == p.N) ? 1u : 2u;
+    int cur = -1;
+    unsigned cnt = 0;
+    double lo = 1.0, hi = 0.0;
+    for (int kx = 0; kx < p.N; ++kx) {
+      const double s = (k2[kx] + k2y) + k2z;
+      if (!(s >= lo && s < hi)) {
+        if (cur >= 0) atomicAdd(&hcnt[cur], cnt * w);
+        cnt = 0;
+        int bi = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
+        bi = min(max(bi, 0), p.nbins - 1);
+        while (bi > 0 && s < thr[bi]) --bi;
+        while (bi < p.nbins - 1 && s >= thr[bi + 1]) ++bi;
+        lo = thr[bi];
+        hi = thr[bi + 1];
+        cur = bi;
+        if (s < lo) {
+          cur = -1; hi = lo; lo = -INFINITY;
+        } else if (s >= hi) {
+          cur = -1; lo = hi; hi = INFINITY;
+        }
+      }
+      if (cur >= 0) ++cnt;
+    }
+    if (cur >= 0) atomicAdd(&hcnt[cur], cnt * w);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < p.nbins; i += blockDim.x) {
+    const unsigned c = hcnt[i];
+    if (c) atomicAdd(&p.nsample[i], (unsigned long long)c);
   }
 }
 
@@ -519,7 +594,7 @@ int launch_x(vps_ctx* ctx, const XParams& p) {
   constexpr int T = xpass_T<NC>();
   typedef PlanInfo<NC> PI;
   size_t lds = (((PI::TW + 1) & ~1) + (size_t)T * PI::PITCH) * sizeof(cf);
-  if (MODE == 0) lds += (size_t)(2 * p.nbins + 1) * sizeof(double) + (size_t)p.nbins * sizeof(unsigned);
+  if (MODE == 0) lds += (size_t)(2 * p.nbins + 1) * sizeof(double);
   if (lds > ctx->lds_per_cu) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "x pass needs %zu B LDS", lds);
   const bool seg = p.seglen != NC;
   auto kern = seg ? fft_x_pass<NC, T, MODE, true> : fft_x_pass<NC, T, MODE, false>;
@@ -706,9 +781,9 @@ int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const
   if ((1 << p.seg_shift) != p.seglen) return vps_fail(ctx, VPS_ERR_ARG, "nseg=%d must be a power of two", nseg);
   p.seg_stride = seg_stride;
   p.tw_stage = tx.tw_stage;
-  if (mode == 0) {
+  if (mode == 0 || mode == 3) {
     if (ctx->bin_N != N || !ctx->d_k2) return vps_fail(ctx, VPS_ERR_ARG, "vps_set_binning(N=%d) has not been called", N);
-    if (!psum_dev || !nsample_dev) return vps_fail(ctx, VPS_ERR_ARG, "null accumulator");
+    if (!psum_dev || (mode == 0 && !nsample_dev)) return vps_fail(ctx, VPS_ERR_ARG, "null accumulator");
     const long long maxline = line0 + nlines - 1;
     if (kz0 + (int)(maxline / N) > N / 2) return vps_fail(ctx, VPS_ERR_ARG, "kz range exceeds N/2");
     p.k2 = ctx->d_k2;
@@ -717,8 +792,28 @@ int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const
     p.edge0 = (float)ctx->edge0;
     p.inv_spacing = (float)ctx->inv_spacing;
     p.psum = psum_dev;
-    p.nsample = nsample_dev;
     VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 0>(ctx, p)));
+    if (rc == VPS_OK && mode == 0) {
+      CountParams c{};
+      c.nlines = nlines;
+      c.line0 = line0;
+      c.N = N;
+      c.kz0 = kz0;
+      c.k2 = ctx->d_k2;
+      c.thr = ctx->d_thr;
+      c.nbins = ctx->nbins;
+      c.edge0 = p.edge0;
+      c.inv_spacing = p.inv_spacing;
+      c.nsample = nsample_dev;
+      const size_t lds = sizeof(double) * (size_t)(ctx->nbins + 1 + N) + sizeof(unsigned) * (size_t)ctx->nbins;
+      long long blocks = (nlines + 255) / 256;
+      if (blocks > (long long)ctx->num_cu * 8) blocks = (long long)ctx->num_cu * 8;
+      {
+        vps_launch_timer tm(ctx, VPS_K_MISC);
+        hipLaunchKernelGGL(count_modes_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, c);
+      }
+      VPS_HIP_CHECK(ctx, hipGetLastError());
+    }
   } else if (mode == 1) {
     if (!out_dev) return vps_fail(ctx, VPS_ERR_ARG, "null output");
     VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 1>(ctx, p)));
@@ -726,7 +821,7 @@ int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const
     if (!out_dev) return vps_fail(ctx, VPS_ERR_ARG, "null output");
     VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 2>(ctx, p)));
   } else {
-    return vps_fail(ctx, VPS_ERR_ARG, "mode must be 0, 1 or 2");
+    return vps_fail(ctx, VPS_ERR_ARG, "mode must be 0, 1, 2 or 3");
   }
   return rc;
 }

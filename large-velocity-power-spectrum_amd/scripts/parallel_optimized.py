@@ -133,7 +133,7 @@ def velocity_spectrum(coords, mass, velocity, ntot, ltot, comm=None, kernels=Non
     vel = k.to_device(np.asarray(velocity, dtype=np.float32))
     grid, _ = k.nn_resample(pos, vel, (ax, ax, ax), pipe.x0, pipe.nx)
     psum, ns = pipe.accumulate([grid[0], grid[1], grid[2]])
-    tab = pipe.finish(psum, ns, 3)
+    tab = pipe.finish(psum, ns)
     tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2
     tab = np.array(tab, dtype=np.float32)                       # :436
     with warnings.catch_warnings():

@@ -273,10 +273,11 @@ class HipKernels:
                                       self._ptr(nyq), self._ptr(work)))
         return spec, nyq
 
-    def fft_x_bin(self, lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample):
+    def fft_x_bin(self, lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True):
+        """x pass + shell sums into psum; with `count` also the shell counts into nsample."""
         self._stream()
         self._chk(self.lib.vps_fft_x(self.ctx, N, nlines, line0, kz0, self._ptr(lines, torch.complex64), nseg,
-                                     seg_stride, 0, self._ptr(psum, torch.float64),
+                                     seg_stride, 0 if count else 3, self._ptr(psum, torch.float64),
                                      self._ptr(nsample, torch.int64), None))
 
     def fft_x_write(self, lines, N, nlines, nseg, seg_stride, out):
@@ -426,8 +427,10 @@ class PowerPipeline:
         self.const = (self.Lbox / (2 * np.pi)) ** 1.5 / self.N ** 3   # interp.py:1381
 
     # -- stage B + C on one or more real fields of this rank's slab ---------------
-    def accumulate(self, fields, psum=None, nsample=None):
-        """Add sum_w |F|^2 of every field ([nx,N,N] float32) into the shell accumulators.
+    def accumulate(self, fields, psum=None, nsample=None, count=True):
+        """Add sum_w |F|^2 of every field ([nx,N,N] float32) into the shell sums, and (with
+        `count`) the number of modes per shell into nsample -- once, on the first field: the
+        reference histograms the component-summed P grid once (interp.py:1474-1477).
         Returns LOCAL (this rank's) accumulators; call `finish` to reduce them."""
         N, nx, G, r = self.N, self.nx, self.comm.world, self.comm.rank
         k = self.k
@@ -437,23 +440,23 @@ class PowerPipeline:
             nsample = k.zeros((self.nbins,), torch.int64)
         nkz = N // 2 // G      # kz rows per rank after the exchange
         nky = N // G           # Nyquist-plane ky rows per rank
-        for f in fields:
+        for i, f in enumerate(fields):
+            c = count and i == 0
             spec, nyq = k.fft_zy(f, N, nx)
             spec = self.comm.all_to_all(spec)
             nyq = self.comm.all_to_all(nyq)
-            k.fft_x_bin(spec, N, nkz * N, 0, r * nkz, G, nkz * N * nx, psum, nsample)
-            k.fft_x_bin(nyq, N, nky, r * nky, N // 2, G, nky * nx, psum, nsample)
+            k.fft_x_bin(spec, N, nkz * N, 0, r * nkz, G, nkz * N * nx, psum, nsample, count=c)
+            k.fft_x_bin(nyq, N, nky, r * nky, N // 2, G, nky * nx, psum, nsample, count=c)
         return psum, nsample
 
-    def finish(self, psum, nsample, ncomp_counted):
+    def finish(self, psum, nsample):
         """Reduce over ranks and build the reference's (nbins,4) table
         [centre, P, Psum, Nsample] (interp.py:1478-1480 / parallel_optimized.py:185-188),
-        before the 4 pi k^2 factor.  `ncomp_counted`: how many fields were accumulated
-        into `nsample` (each field counts every mode once)."""
+        before the 4 pi k^2 factor."""
         self.comm.all_reduce_sum(psum)
         self.comm.all_reduce_sum(nsample)
         ps = psum.cpu().numpy() * (0.5 * self.const ** 2)
-        ns = nsample.cpu().numpy() // max(int(ncomp_counted), 1)
+        ns = nsample.cpu().numpy()
         with np.errstate(invalid="ignore", divide="ignore"):
             P = ps / ns
         if self.flavour == "library":
@@ -462,6 +465,6 @@ class PowerPipeline:
 
     def spectrum(self, fields):
         psum, nsample = self.accumulate(fields)
-        tab = self.finish(psum, nsample, len(fields))
+        tab = self.finish(psum, nsample)
         tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2   # interp.py:590 / parallel_optimized.py:434
         return tab

@@ -42,7 +42,7 @@ class OracleKernels:
                 for g in range(nseg)]
         return np.concatenate(segs, axis=1)
 
-    def fft_x_bin(self, lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample):
+    def fft_x_bin(self, lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True):
         Nb, k2, thr = self.binning
         assert Nb == N
         L = np.fft.fft(self._lines(lines, N, nlines, nseg, seg_stride).astype(np.complex128), axis=1)
@@ -58,4 +58,5 @@ class OracleKernels:
         ps = np.bincount(b[ok], weights=(pw * w)[ok], minlength=nb)
         ns = np.bincount(b[ok], weights=w[ok], minlength=nb)
         psum += torch.from_numpy(ps)
-        nsample += torch.from_numpy(np.rint(ns).astype(np.int64))
+        if count:
+            nsample += torch.from_numpy(np.rint(ns).astype(np.int64))

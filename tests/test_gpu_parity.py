@@ -327,7 +327,7 @@ def test_config2_properties(K):
     K.field_algebra(grid, device.VELOCITY, 0, L / N)
     pipe = device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False))
     fields = [grid[0], grid[1], grid[2]]
-    tab = pipe.finish(*pipe.accumulate(fields), 3)
+    tab = pipe.finish(*pipe.accumulate(fields))
     # every mode except k=0 and the corners beyond kmax+kres/2 is counted exactly once
     ks = device.k_axis(L, N)
     k2 = ks * ks
@@ -342,7 +342,7 @@ def test_config2_properties(K):
     total = tab[:, 2].sum() * (2 * np.pi / L) ** 3
     assert 0.5 * v2 * 0.45 < total <= 0.5 * v2 * (1 + 1e-5)      # corners hold < 55% of white noise
     # linearity: P(2 f) = 4 P(f), bit-for-bit equal Nsample
-    tab2 = pipe.finish(*pipe.accumulate([2 * fields[0]]), 1)
-    tab1 = pipe.finish(*pipe.accumulate([fields[0]]), 1)
+    tab2 = pipe.finish(*pipe.accumulate([2 * fields[0]]))
+    tab1 = pipe.finish(*pipe.accumulate([fields[0]]))
     assert np.array_equal(tab1[:, 3], tab2[:, 3])
     assert np.allclose(tab2[:, 2], 4 * tab1[:, 2], rtol=1e-6)

@@ -100,12 +100,12 @@ def test_threshold_binning_equals_reference_nsample():
         k = OracleKernels()
         pipe = device.PowerPipeline(N, 1.0, kernels=k, comm=device.SlabComm(enabled=False))
         psum, ns = pipe.accumulate([torch.ones((N, N, N), dtype=torch.float32)])
-        tab = pipe.finish(psum, ns, 1)
+        tab = pipe.finish(psum, ns)
         assert np.array_equal(tab[:, 3].astype(np.int64), g[key])
     k = OracleKernels()
     pipe = device.PowerPipeline(32, 2.5, kernels=k, comm=device.SlabComm(enabled=False))
     psum, ns = pipe.accumulate([torch.ones((32, 32, 32), dtype=torch.float32)])
-    assert np.array_equal(pipe.finish(psum, ns, 1)[:, 3].astype(np.int64), g["library_32_L2p5"])
+    assert np.array_equal(pipe.finish(psum, ns)[:, 3].astype(np.int64), g["library_32_L2p5"])
 
 
 def test_pipeline_host_math_against_oracle_single_rank():
