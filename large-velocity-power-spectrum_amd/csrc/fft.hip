@@ -364,28 +364,36 @@ struct XParams {
   int nbins;
   float edge0, inv_spacing;
   double* psum;
+  unsigned long long* nsample;
 };
 
-template <int NC, int T, int MODE, bool SEG>
+template <int NC, int T, int MODE, bool SEG, bool COUNT>
 __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p) {
   typedef PlanInfo<NC> PI;
   constexpr int L = PI::L, RL = PI::RL, NT = T * L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  // carve: thr (double) | hsum (double) | tw | line buffers
+  // carve: thr (double) | hsum (double) | tw | line buffers | hcnt
   double* thr = reinterpret_cast<double*>(smem_raw);
   double* hsum = thr + (MODE == 0 ? (p.nbins + 1) : 0);
   cf* tw = reinterpret_cast<cf*>(hsum + (MODE == 0 ? p.nbins : 0));
   cf* buf = tw + ((PI::TW + 1) & ~1);
+  unsigned* hcnt = reinterpret_cast<unsigned*>(buf + T * PI::PITCH);
 
   const int tid = threadIdx.x;
   const int t = tid / L, l = tid % L;
   for (int i = tid; i < PI::TW; i += NT) tw[i] = p.tw_stage[i];
-  double k2x[MODE == 0 ? RL : 1];   // fl(kx*kx) of this lane's contiguous chunk of kx
+  // fl(kx*kx) of this lane's contiguous chunk of RL kx values, ordered by non-decreasing
+  // |kx|: the chunks of the negative-frequency half (index >= NC/2) are walked backwards
+  double k2x[MODE == 0 ? RL : 1];
+  const bool rev = (l * RL) >= NC / 2;
   if constexpr (MODE == 0) {
     for (int i = tid; i <= p.nbins; i += NT) thr[i] = p.thr[i];
-    for (int i = tid; i < p.nbins; i += NT) hsum[i] = 0.0;
+    for (int i = tid; i < p.nbins; i += NT) {
+      hsum[i] = 0.0;
+      if constexpr (COUNT) hcnt[i] = 0u;
+    }
 #pragma unroll
-    for (int i = 0; i < RL; ++i) k2x[i] = p.k2[l * RL + i];
+    for (int i = 0; i < RL; ++i) k2x[i] = p.k2[l * RL + (rev ? RL - 1 - i : i)];
   }
   __syncthreads();
 
@@ -445,33 +453,51 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
         const int ky = (int)(g % p.N);
         const int kz = p.kz0 + (int)(g / p.N);
         const double k2y = p.k2[ky], k2z = p.k2[kz];
-        const double wd = (kz == 0 || 2 * kz == p.N) ? 1.0 : 2.0;
-        const float* mine = pw + l * (RL + 1);
-        int cur = -1;
-        double lo = 1.0, hi = 0.0, acc = 0.0;   // empty interval: first element searches
+        const unsigned w = (kz == 0 || 2 * kz == p.N) ? 1u : 2u;
+        const double wd = (double)w;
+        // walk the chunk in the direction of non-decreasing |kx| (k2x was loaded that way)
+        const float* mine = pw + l * (RL + 1) + (rev ? RL - 1 : 0);
+        const int step = rev ? -1 : 1;
+        // shell of the first element: thr[cur] <= s < thr[cur+1], cur = -1 / nbins outside
+        double s = (k2x[0] + k2y) + k2z;
+        int cur = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
+        cur = min(max(cur, 0), p.nbins - 1);
+        while (cur > 0 && s < thr[cur]) --cur;
+        while (cur < p.nbins - 1 && s >= thr[cur + 1]) ++cur;
+        if (s < thr[cur]) cur = -1;
+        else if (s >= thr[cur + 1]) cur = p.nbins;
+        double hi = (cur < p.nbins) ? thr[cur + 1] : INFINITY;
+        double lo = (cur >= 0) ? thr[cur] : -INFINITY;
+        double acc = 0.0;
+        unsigned cnt = 0;
+        auto flush = [&]() {   // one LDS atomic per (lane, shell) run
+          if (cur >= 0 && cur < p.nbins) {
+            atomicAdd(&hsum[cur], acc * wd);
+            if constexpr (COUNT) atomicAdd(&hcnt[cur], cnt * w);
+          }
+          acc = 0.0;
+          cnt = 0;
+        };
 #pragma unroll
         for (int i = 0; i < RL; ++i) {
           // s = (kx*kx + ky*ky) + kz*kz with numpy's rounding (the table holds fl(k*k))
-          const double s = (k2x[i] + k2y) + k2z;
-          if (!(s >= lo && s < hi)) {
-            if (cur >= 0) atomicAdd(&hsum[cur], acc * wd);
-            acc = 0.0;
-            int bi = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
-            bi = min(max(bi, 0), p.nbins - 1);
-            while (bi > 0 && s < thr[bi]) --bi;
-            while (bi < p.nbins - 1 && s >= thr[bi + 1]) ++bi;
-            lo = thr[bi];
-            hi = thr[bi + 1];
-            cur = bi;
-            if (s < lo) {          // below the first edge (e.g. the k = 0 mode)
-              cur = -1; hi = lo; lo = -INFINITY;
-            } else if (s >= hi) {  // beyond the last edge (corner modes)
-              cur = -1; lo = hi; hi = INFINITY;
-            }
+          s = (k2x[i] + k2y) + k2z;
+          while (s >= hi) {   // moved outwards to the next shell (the usual direction)
+            flush();
+            ++cur;
+            lo = hi;
+            hi = (cur < p.nbins) ? thr[cur + 1] : INFINITY;
           }
-          if (cur >= 0) acc += (double)mine[i];
+          while (s < lo) {    // only for chunks that are not monotone in |kx| (N = 16)
+            flush();
+            --cur;
+            hi = lo;
+            lo = (cur >= 0) ? thr[cur] : -INFINITY;
+          }
+          acc += (double)mine[i * step];
+          ++cnt;
         }
-        if (cur >= 0) atomicAdd(&hsum[cur], acc * wd);
+        flush();
       }
     }
   }
@@ -480,69 +506,11 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
     for (int i = tid; i < p.nbins; i += NT) {
       const double hs = hsum[i];
       if (hs != 0.0) atomicAdd(&p.psum[i], hs);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------
-// Shell COUNTS of the same lines (input independent): one thread walks one line and adds
-// each run of equal bins with one LDS atomic.  Same s / threshold arithmetic as above.
-// ------------------------------------------------------------------------------
-struct CountParams {
-  long long nlines, line0;
-  int N, kz0;
-  const double* k2;
-  const double* thr;
-  int nbins;
-  float edge0, inv_spacing;
-  unsigned long long* nsample;
-};
-
-__global__ void __launch_bounds__(256) count_modes_kernel(const CountParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* thr = reinterpret_cast<double*>(smem_raw);
-  double* k2 = thr + p.nbins + 1;
-  unsigned* hcnt = reinterpret_cast<unsigned*>(k2 + p.N);
-  for (int i = threadIdx.x; i <= p.nbins; i += blockDim.x) thr[i] = p.thr[i];
-  for (int i = threadIdx.x; i < p.N; i += blockDim.x) k2[i] = p.k2[i];
-  for (int i = threadIdx.x; i < p.nbins; i += blockDim.x) hcnt[i] = 0u;
-  __syncthreads();
-  for (long long li = (long long)blockIdx.x * blockDim.x + threadIdx.x; li < p.nlines;
-       li += (long long)gridDim.x * blockDim.x) {
-    const long long g = p.line0 + li;
-    const int ky = (int)(g % p.N);
-    const int kz = p.kz0 + (int)(g / p.N);
-    const double k2y = k2[ky], k2z = k2[kz];
-    const unsigned w = (kz == 0 || 2 * kz == p.N) ? 1u : 2u;
-    int cur = -1;
-    unsigned cnt = 0;
-    double lo = 1.0, hi = 0.0;
-    for (int kx = 0; kx < p.N; ++kx) {
-      const double s = (k2[kx] + k2y) + k2z;
-      if (!(s >= lo && s < hi)) {
-        if (cur >= 0) atomicAdd(&hcnt[cur], cnt * w);
-        cnt = 0;
-        int bi = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
-        bi = min(max(bi, 0), p.nbins - 1);
-        while (bi > 0 && s < thr[bi]) --bi;
-        while (bi < p.nbins - 1 && s >= thr[bi + 1]) ++bi;
-        lo = thr[bi];
-        hi = thr[bi + 1];
-        cur = bi;
-        if (s < lo) {
-          cur = -1; hi = lo; lo = -INFINITY;
-        } else if (s >= hi) {
-          cur = -1; lo = hi; hi = INFINITY;
-        }
+      if constexpr (COUNT) {
+        const unsigned c = hcnt[i];
+        if (c) atomicAdd(&p.nsample[i], (unsigned long long)c);
       }
-      if (cur >= 0) ++cnt;
     }
-    if (cur >= 0) atomicAdd(&hcnt[cur], cnt * w);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < p.nbins; i += blockDim.x) {
-    const unsigned c = hcnt[i];
-    if (c) atomicAdd(&p.nsample[i], (unsigned long long)c);
   }
 }
 
@@ -589,15 +557,15 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
   return VPS_OK;
 }
 
-template <int NC, int MODE>
+template <int NC, int MODE, bool COUNT = false>
 int launch_x(vps_ctx* ctx, const XParams& p) {
   constexpr int T = xpass_T<NC>();
   typedef PlanInfo<NC> PI;
   size_t lds = (((PI::TW + 1) & ~1) + (size_t)T * PI::PITCH) * sizeof(cf);
-  if (MODE == 0) lds += (size_t)(2 * p.nbins + 1) * sizeof(double);
+  if (MODE == 0) lds += (size_t)(2 * p.nbins + 1) * sizeof(double) + (COUNT ? (size_t)p.nbins * sizeof(unsigned) : 0);
   if (lds > ctx->lds_per_cu) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "x pass needs %zu B LDS", lds);
   const bool seg = p.seglen != NC;
-  auto kern = seg ? fft_x_pass<NC, T, MODE, true> : fft_x_pass<NC, T, MODE, false>;
+  auto kern = seg ? fft_x_pass<NC, T, MODE, true, COUNT> : fft_x_pass<NC, T, MODE, false, COUNT>;
   if (lds > 64 * 1024)
     VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -792,27 +760,11 @@ int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const
     p.edge0 = (float)ctx->edge0;
     p.inv_spacing = (float)ctx->inv_spacing;
     p.psum = psum_dev;
-    VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 0>(ctx, p)));
-    if (rc == VPS_OK && mode == 0) {
-      CountParams c{};
-      c.nlines = nlines;
-      c.line0 = line0;
-      c.N = N;
-      c.kz0 = kz0;
-      c.k2 = ctx->d_k2;
-      c.thr = ctx->d_thr;
-      c.nbins = ctx->nbins;
-      c.edge0 = p.edge0;
-      c.inv_spacing = p.inv_spacing;
-      c.nsample = nsample_dev;
-      const size_t lds = sizeof(double) * (size_t)(ctx->nbins + 1 + N) + sizeof(unsigned) * (size_t)ctx->nbins;
-      long long blocks = (nlines + 255) / 256;
-      if (blocks > (long long)ctx->num_cu * 8) blocks = (long long)ctx->num_cu * 8;
-      {
-        vps_launch_timer tm(ctx, VPS_K_MISC);
-        hipLaunchKernelGGL(count_modes_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, c);
-      }
-      VPS_HIP_CHECK(ctx, hipGetLastError());
+    p.nsample = nsample_dev;
+    if (mode == 0) {
+      VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 0, true>(ctx, p)));
+    } else {
+      VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 0, false>(ctx, p)));
     }
   } else if (mode == 1) {
     if (!out_dev) return vps_fail(ctx, VPS_ERR_ARG, "null output");
