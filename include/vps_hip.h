@@ -88,11 +88,24 @@ int vps_timing_list(vps_ctx* ctx, int kind, double* ms_out, int64_t cap, int64_t
  * pos_dev: [np][3] float32 (pos_is_f64=0) or float64 (1).                        */
 int vps_cell_index(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, int64_t np,
                    int N, double Lbox, int32_t* cell_dev /* [np][3] */);
-/* payload_dev: [np][C] float32.  grid_dev: [C][nx][N][N] float32, ACCUMULATED into
- * (caller zeroes it); particles whose x cell is outside [x0,x0+nx) are skipped.   */
+/* Two-level bucket deposition (count -> scan -> scatter into per-brick buckets -> one
+ * workgroup per brick accumulates in LDS and streams the tile out).
+ * payload_dev: [np][C] float32, C in {1,3,4}.  grid_dev: [C][nx][N][N] float32 is
+ * OVERWRITTEN: every cell of the slab is written exactly once (no memset needed);
+ * particles whose x cell is outside [x0,x0+nx) are skipped.
+ * work_dev: vps_deposit_workspace_bytes(np, C, N, nx) bytes of scratch.              */
+size_t vps_deposit_workspace_bytes(int64_t np, int C, int N, int nx);
 int vps_deposit_ngp(vps_ctx* ctx, const void* pos_dev, int pos_is_f64,
                     const float* payload_dev, int64_t np, int C,
-                    int N, double Lbox, int x0, int nx, float* grid_dev);
+                    int N, double Lbox, int x0, int nx, float* grid_dev, void* work_dev);
+/* The fused hot-path form: deposits density_velocity_vector (interp.py:199-213) built on
+ * the fly from vel_dev [np][3] and rho_dev [np], and applies the field algebra of
+ * vps_field_algebra in the brick epilogue.  fields_dev: [ncomp][nx][N][N] float32,
+ * ncomp = 3 (VPS_VELOCITY, VPS_MOMENTUM), 1 (VPS_ENERGY) or 4 (VPS_VM: vx,vy,vz,mass).
+ * work_dev: vps_deposit_workspace_bytes(np, 4, N, nx).                              */
+int vps_deposit_field(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
+                      const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx,
+                      int quantity, int flags, float* fields_dev, void* work_dev);
 
 /* out_dev[np][4] = [vx*rho, vy*rho, vz*rho, rho]: GasParticles.density_velocity_vector
  * (vpower/interp.py:199-213).  vel_dev [np][3], rho_dev [np], float32.             */

@@ -1,8 +1,21 @@
 // Stage A1 (nearest-grid-point deposition) and A3 (field algebra).
 //
-// Replaces deposit_to_grid (vpower/interp.py:996-1015) and the elementwise steps
-// of ann_interp_to_field / BoxField.{momentum,kinetic_energy}_power
-// (vpower/interp.py:272-273, 523-525, 546).
+// Replaces deposit_to_grid (vpower/interp.py:996-1015), density_velocity_vector
+// (:199-213) and the elementwise steps of ann_interp_to_field /
+// BoxField.{momentum,kinetic_energy}_power (:272-273, 523-525, 546).
+//
+// Deposition is a two-level bucket scheme built for HBM3E + 160 KiB LDS:
+//   1. count   : one pass over the particles, histogram of BRICK ids (a brick is a
+//                bx*by*bz block of cells whose C float channels fit a 64 KiB LDS tile);
+//   2. scan    : exclusive prefix sum of the brick counts;
+//   3. scatter : second pass, each particle's record {cell-in-brick, payload[C]} is
+//                written into its brick's contiguous bucket;
+//   4. bricks  : one workgroup per brick adds its bucket into an LDS tile with LDS
+//                float atomics and then streams the WHOLE tile out with full-width
+//                coalesced stores (rows of bz cells), applying the field algebra
+//                (v = rho v / rho, momentum, kinetic energy) on the way out.
+// Every cell of the slab is therefore written exactly once by plain stores: there is no
+// grid memset, no global float atomic and no separate algebra pass.
 //
 // Cell indices must be BIT EXACT with numpy's  int((pos // Lcell) % N)  (SURVEY.md
 // Q13): numpy evaluates floor_divide and remainder with its divmod algorithm in the
@@ -11,6 +24,7 @@
 #pragma clang fp contract(off)
 
 #include "vps_internal.h"
+#include "scan.h"
 
 namespace {
 
@@ -69,32 +83,202 @@ __global__ void __launch_bounds__(256) cell_index_kernel(const F* __restrict__ p
   for (int a = 0; a < 3; ++a) cell[i * 3 + a] = cell_of<F>(pos[i * 3 + a], lcell, nsize);
 }
 
-// One thread per particle, C float atomics into the channel-major slab grid.
-// Sparse regime of the BASELINE configs (<= 0.08 particles per cell): collisions are
-// rare, the cost is the scattered read-modify-write traffic itself.
-template <typename F, int C>
-__global__ void __launch_bounds__(256)
-    deposit_ngp_kernel(const F* __restrict__ pos, const float* __restrict__ payload, long long np,
-                       F lcell, F nsize, int N, int x0, int nx, float* __restrict__ grid) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= np) return;
-  const int cx = cell_of<F>(pos[i * 3 + 0], lcell, nsize) - x0;
-  if (cx < 0 || cx >= nx) return;
+// ---- brick geometry ------------------------------------------------------------
+struct Bricks {
+  int N, x0, nx;        // grid and slab
+  int bx, by, bz;       // brick extent in cells
+  int nbx, nby, nbz;    // bricks per axis of the slab
+  int cells;            // bx*by*bz
+};
+
+// brick id and cell-in-brick of a particle, or false when it is outside the slab
+template <typename F>
+__device__ __forceinline__ bool locate(const F* __restrict__ pos, long long i, F lcell, F nsize,
+                                       const Bricks& b, unsigned& brick, unsigned& loc) {
+  const int cx = cell_of<F>(pos[i * 3 + 0], lcell, nsize) - b.x0;
+  if (cx < 0 || cx >= b.nx) return false;
   const int cy = cell_of<F>(pos[i * 3 + 1], lcell, nsize);
   const int cz = cell_of<F>(pos[i * 3 + 2], lcell, nsize);
-  if ((unsigned)cy >= (unsigned)N || (unsigned)cz >= (unsigned)N) return;  // NaN / inf positions
-  const long long cell = ((long long)cx * N + cy) * N + cz;
-  const long long plane = (long long)nx * N * N;
+  if ((unsigned)cy >= (unsigned)b.N || (unsigned)cz >= (unsigned)b.N) return false;  // NaN / inf
+  const int ix = cx / b.bx, iy = cy / b.by, iz = cz / b.bz;
+  brick = (unsigned)((ix * b.nby + iy) * b.nbz + iz);
+  loc = (unsigned)(((cx - ix * b.bx) * b.by + (cy - iy * b.by)) * b.bz + (cz - iz * b.bz));
+  return true;
+}
+
+template <typename F>
+__global__ void __launch_bounds__(256)
+    brick_count_kernel(const F* __restrict__ pos, long long np, F lcell, F nsize, Bricks b,
+                       unsigned* __restrict__ count) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  unsigned brick, loc;
+  if (locate<F>(pos, i, lcell, nsize, b, brick, loc)) atomicAdd(&count[brick], 1u);
+}
+
+// record = {loc, payload[C]} as (C+1) 32-bit words.  RHOV: payload is built from velocity
+// and density on the fly ([rho vx, rho vy, rho vz, rho], interp.py:199-213).
+template <typename F, int C, bool RHOV>
+__global__ void __launch_bounds__(256)
+    brick_scatter_kernel(const F* __restrict__ pos, const float* __restrict__ payload,
+                         const float* __restrict__ rho, long long np, F lcell, F nsize, Bricks b,
+                         const unsigned* __restrict__ start, unsigned* __restrict__ fill,
+                         unsigned* __restrict__ records) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  unsigned brick, loc;
+  if (!locate<F>(pos, i, lcell, nsize, b, brick, loc)) return;
   float val[C];
-  if constexpr (C == 4) {
+  if constexpr (RHOV) {
+    static_assert(C == 4, "rho*v payload has four channels");
+    const float r = rho[i];
+    val[0] = payload[i * 3 + 0] * r;
+    val[1] = payload[i * 3 + 1] * r;
+    val[2] = payload[i * 3 + 2] * r;
+    val[3] = r;
+  } else if constexpr (C == 4) {
     const float4 p4 = *reinterpret_cast<const float4*>(payload + i * 4);
     val[0] = p4.x; val[1] = p4.y; val[2] = p4.z; val[3] = p4.w;
   } else {
 #pragma unroll
     for (int c = 0; c < C; ++c) val[c] = payload[i * C + c];
   }
+  const unsigned slot = start[brick] + atomicAdd(&fill[brick], 1u);
+  unsigned* rec = records + (size_t)slot * (C + 1);
+  rec[0] = loc;
 #pragma unroll
-  for (int c = 0; c < C; ++c) atomicAdd(grid + c * plane + cell, val[c]);
+  for (int c = 0; c < C; ++c) rec[1 + c] = __float_as_uint(val[c]);
+}
+
+// Epilogue of the brick kernel: what is written for a cell from its C accumulated channels.
+//   EPI_RAW      : the C channels as they are (deposit_to_grid)
+//   EPI_ALGEBRA  : channels are [rho vx, rho vy, rho vz, rho] -> fields of `quantity`
+enum { EPI_RAW = 0, EPI_ALGEBRA = 1 };
+
+__device__ __forceinline__ void algebra_cell(float a, float b, float c, float rho, int quantity, int flags,
+                                             float vol, float out[4]) {
+  // v = (rho v)/rho; empty cells give 0 (the NaN->0 rule of interp.py:329-331)
+  float vx, vy, vz, m;
+  if (flags & VPS_FLAG_INPUT_IS_VM) {
+    vx = a; vy = b; vz = c; m = rho;
+  } else {
+    vx = rho != 0.f ? a / rho : 0.f;
+    vy = rho != 0.f ? b / rho : 0.f;
+    vz = rho != 0.f ? c / rho : 0.f;
+    m = rho * vol;
+  }
+  if (quantity == VPS_MOMENTUM) {
+    out[0] = vx * m;
+    out[1] = ((flags & VPS_FLAG_REFERENCE_MOMENTUM_BUG) ? vx : vy) * m;
+    out[2] = ((flags & VPS_FLAG_REFERENCE_MOMENTUM_BUG) ? vx : vz) * m;
+    out[3] = m;
+  } else if (quantity == VPS_ENERGY) {
+    out[0] = m * ((vx * vx + vy * vy) + vz * vz);
+    out[1] = out[2] = 0.f;
+    out[3] = m;
+  } else {  // VPS_VELOCITY, VPS_VM
+    out[0] = vx; out[1] = vy; out[2] = vz; out[3] = m;
+  }
+}
+
+__host__ __device__ inline int quantity_channels(int quantity) {
+  return quantity == VPS_ENERGY ? 1 : (quantity == VPS_VM ? 4 : 3);
+}
+
+template <int C, int EPI>
+__global__ void __launch_bounds__(256)
+    brick_accumulate_kernel(const unsigned* __restrict__ records, const unsigned* __restrict__ start,
+                            Bricks b, int quantity, int flags, float vol, float* __restrict__ grid) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* tile = reinterpret_cast<float*>(smem_raw);  // [C][cells]
+  const int cells = b.cells;
+  for (int i = threadIdx.x; i < C * cells; i += blockDim.x) tile[i] = 0.f;
+  __syncthreads();
+  const unsigned brick = blockIdx.x;
+  const unsigned s = start[brick], e = start[brick + 1];
+  for (unsigned j = s + threadIdx.x; j < e; j += blockDim.x) {
+    const unsigned* rec = records + (size_t)j * (C + 1);
+    const unsigned loc = rec[0];
+#pragma unroll
+    for (int c = 0; c < C; ++c) atomicAdd(&tile[c * cells + loc], __uint_as_float(rec[1 + c]));
+  }
+  __syncthreads();
+  // stream the tile out: rows of bz cells are contiguous in the grid
+  const int iz = brick % b.nbz, iy = (brick / b.nbz) % b.nby, ix = brick / (b.nbz * b.nby);
+  const int gx0 = ix * b.bx, gy0 = iy * b.by, gz0 = iz * b.bz;
+  const long long plane = (long long)b.nx * b.N * b.N;
+  const int nout = (EPI == EPI_RAW) ? C : quantity_channels(quantity);
+  const bool vec4 = ((b.bz & 3) == 0) && ((b.N & 3) == 0);
+  if (vec4) {
+    const int q4 = cells / 4;
+    for (int i = threadIdx.x; i < q4; i += blockDim.x) {
+      const int loc = i * 4;
+      const int lz = loc % b.bz, ly = (loc / b.bz) % b.by, lx = loc / (b.bz * b.by);
+      const int gx = gx0 + lx, gy = gy0 + ly, gz = gz0 + lz;
+      if (gx >= b.nx || gy >= b.N || gz >= b.N) continue;   // partial bricks at the slab edge
+      const long long cell = ((long long)gx * b.N + gy) * b.N + gz;
+      float4 ch[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) ch[c] = *reinterpret_cast<const float4*>(tile + c * cells + loc);
+      if constexpr (EPI == EPI_RAW) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) *reinterpret_cast<float4*>(grid + c * plane + cell) = ch[c];
+      } else {
+        float4 o[4];
+        float r[4];
+        algebra_cell(ch[0].x, ch[1].x, ch[2].x, ch[3].x, quantity, flags, vol, r);
+        o[0].x = r[0]; o[1].x = r[1]; o[2].x = r[2]; o[3].x = r[3];
+        algebra_cell(ch[0].y, ch[1].y, ch[2].y, ch[3].y, quantity, flags, vol, r);
+        o[0].y = r[0]; o[1].y = r[1]; o[2].y = r[2]; o[3].y = r[3];
+        algebra_cell(ch[0].z, ch[1].z, ch[2].z, ch[3].z, quantity, flags, vol, r);
+        o[0].z = r[0]; o[1].z = r[1]; o[2].z = r[2]; o[3].z = r[3];
+        algebra_cell(ch[0].w, ch[1].w, ch[2].w, ch[3].w, quantity, flags, vol, r);
+        o[0].w = r[0]; o[1].w = r[1]; o[2].w = r[2]; o[3].w = r[3];
+        for (int c = 0; c < nout; ++c) *reinterpret_cast<float4*>(grid + c * plane + cell) = o[c];
+      }
+    }
+  } else {
+    for (int loc = threadIdx.x; loc < cells; loc += blockDim.x) {
+      const int lz = loc % b.bz, ly = (loc / b.bz) % b.by, lx = loc / (b.bz * b.by);
+      const int gx = gx0 + lx, gy = gy0 + ly, gz = gz0 + lz;
+      if (gx >= b.nx || gy >= b.N || gz >= b.N) continue;
+      const long long cell = ((long long)gx * b.N + gy) * b.N + gz;
+      if constexpr (EPI == EPI_RAW) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) grid[c * plane + cell] = tile[c * cells + loc];
+      } else {
+        float r[4];
+        algebra_cell(tile[loc], tile[cells + loc], tile[2 * cells + loc], tile[3 * cells + loc], quantity,
+                     flags, vol, r);
+        for (int c = 0; c < nout; ++c) grid[c * plane + cell] = r[c];
+      }
+    }
+  }
+}
+
+// In-place algebra on an existing 4-channel grid (used after the NN resample and by
+// BoxField.spctrm on user-supplied fields).
+__global__ void __launch_bounds__(256)
+    field_algebra_kernel(float* __restrict__ ch, long long ncell, int quantity, int flags, float vol) {
+  const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 >= ncell) return;
+  float4 a = *reinterpret_cast<float4*>(ch + i0);
+  float4 b = *reinterpret_cast<float4*>(ch + ncell + i0);
+  float4 c = *reinterpret_cast<float4*>(ch + 2 * ncell + i0);
+  float4 m = *reinterpret_cast<float4*>(ch + 3 * ncell + i0);
+  float* pa = &a.x; float* pb = &b.x; float* pc = &c.x; float* pm = &m.x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float r[4];
+    algebra_cell(pa[j], pb[j], pc[j], pm[j], quantity, flags, vol, r);
+    pa[j] = r[0]; pb[j] = r[1]; pc[j] = r[2]; pm[j] = r[3];
+  }
+  *reinterpret_cast<float4*>(ch + i0) = a;
+  if (quantity != VPS_ENERGY) {
+    *reinterpret_cast<float4*>(ch + ncell + i0) = b;
+    *reinterpret_cast<float4*>(ch + 2 * ncell + i0) = c;
+  }
+  if (quantity == VPS_VM) *reinterpret_cast<float4*>(ch + 3 * ncell + i0) = m;
 }
 
 // [rho vx, rho vy, rho vz, rho] per particle (interp.py:199-213)
@@ -108,65 +292,96 @@ __global__ void __launch_bounds__(256)
       make_float4(vel[i * 3 + 0] * r, vel[i * 3 + 1] * r, vel[i * 3 + 2] * r, r);
 }
 
-__global__ void __launch_bounds__(256)
-    field_algebra_kernel(float* __restrict__ ch, long long ncell, int quantity, int flags, float vol) {
-  const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i0 >= ncell) return;
-  float4 a = *reinterpret_cast<float4*>(ch + i0);
-  float4 b = *reinterpret_cast<float4*>(ch + ncell + i0);
-  float4 c = *reinterpret_cast<float4*>(ch + 2 * ncell + i0);
-  const float4 r = *reinterpret_cast<float4*>(ch + 3 * ncell + i0);
-  float4 mm = r;
-  float* pa = &a.x; float* pb = &b.x; float* pc = &c.x; float* pm = &mm.x;
-  const float* pr = &r.x;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float vx, vy, vz, m;
-    if (flags & VPS_FLAG_INPUT_IS_VM) {
-      vx = pa[j]; vy = pb[j]; vz = pc[j]; m = pr[j];
-    } else {
-      const float rho = pr[j];
-      // v = (rho v)/rho; empty cells give 0 (the NaN->0 rule of interp.py:329-331)
-      vx = rho != 0.f ? pa[j] / rho : 0.f;
-      vy = rho != 0.f ? pb[j] / rho : 0.f;
-      vz = rho != 0.f ? pc[j] / rho : 0.f;
-      m = rho * vol;
-    }
-    if (quantity == VPS_VELOCITY || quantity == VPS_VM) {
-      pa[j] = vx; pb[j] = vy; pc[j] = vz;
-      pm[j] = m;
-    } else if (quantity == VPS_MOMENTUM) {
-      pa[j] = vx * m;
-      pb[j] = ((flags & VPS_FLAG_REFERENCE_MOMENTUM_BUG) ? vx : vy) * m;
-      pc[j] = ((flags & VPS_FLAG_REFERENCE_MOMENTUM_BUG) ? vx : vz) * m;
-    } else {
-      pa[j] = m * ((vx * vx + vy * vy) + vz * vz);
-    }
-  }
-  *reinterpret_cast<float4*>(ch + i0) = a;
-  if (quantity != VPS_ENERGY) {
-    *reinterpret_cast<float4*>(ch + ncell + i0) = b;
-    *reinterpret_cast<float4*>(ch + 2 * ncell + i0) = c;
-  }
-  if (quantity == VPS_VM) *reinterpret_cast<float4*>(ch + 3 * ncell + i0) = mm;
+int pow2_floor(int v) {
+  int p = 1;
+  while (p * 2 <= v) p *= 2;
+  return p;
 }
 
-template <typename F>
-int deposit_dispatch(vps_ctx* ctx, const void* pos, const float* payload, int64_t np, int C, int N,
-                     double Lbox, int x0, int nx, float* grid) {
+Bricks make_bricks(int N, int x0, int nx, int C) {
+  Bricks b;
+  b.N = N; b.x0 = x0; b.nx = nx;
+  const int max_cells = (64 * 1024) / (4 * C);        // 64 KiB LDS tile
+  b.bz = N < 64 ? N : 64;                              // up to 256-byte rows
+  if (b.bz > max_cells) b.bz = max_cells;
+  int rest = max_cells / b.bz;
+  b.by = pow2_floor(rest < 8 ? (rest < 1 ? 1 : rest) : 8);
+  if (b.by > N) b.by = N;
+  rest = max_cells / (b.bz * b.by);
+  b.bx = pow2_floor(rest < 1 ? 1 : rest);
+  if (b.bx > nx) b.bx = nx;
+  b.nbx = (nx + b.bx - 1) / b.bx;
+  b.nby = (N + b.by - 1) / b.by;
+  b.nbz = (N + b.bz - 1) / b.bz;
+  b.cells = b.bx * b.by * b.bz;
+  return b;
+}
+
+struct DepLayout {
+  size_t count, fill, start, tiles, records, total;
+  long long nbricks;
+};
+
+DepLayout dep_layout(int64_t np, int C, const Bricks& b) {
+  DepLayout l;
+  l.nbricks = (long long)b.nbx * b.nby * b.nbz;
+  auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t off = 0;
+  l.count = off;   off = align(off + sizeof(unsigned) * l.nbricks);
+  l.fill = off;    off = align(off + sizeof(unsigned) * l.nbricks);
+  l.start = off;   off = align(off + sizeof(unsigned) * (l.nbricks + 1));
+  l.tiles = off;   off = align(off + sizeof(unsigned) * (scan_tiles(l.nbricks) + 1));
+  l.records = off; off = align(off + (size_t)np * (C + 1) * sizeof(unsigned));
+  l.total = off;
+  return l;
+}
+
+template <typename F, int C, bool RHOV, int EPI>
+int deposit_run(vps_ctx* ctx, const void* pos_v, const float* payload, const float* rho, int64_t np, int N,
+                double Lbox, int x0, int nx, int quantity, int flags, float* grid, void* work_v) {
+  const F* pos = reinterpret_cast<const F*>(pos_v);
   // Lcell = Lbox/float(N) in double, then cast to the dtype of pos: what numpy's weak
   // Python-float scalar does in `pos // Lcell`
   const F lcell = (F)(Lbox / (double)N);
   const F nsz = (F)N;
-  const unsigned blocks = (unsigned)((np + 255) / 256);
-  vps_launch_timer tm(ctx, VPS_K_DEPOSIT);
-  const F* p = reinterpret_cast<const F*>(pos);
-  switch (C) {
-    case 1: hipLaunchKernelGGL((deposit_ngp_kernel<F, 1>), dim3(blocks), dim3(256), 0, ctx->stream, p, payload, np, lcell, nsz, N, x0, nx, grid); break;
-    case 3: hipLaunchKernelGGL((deposit_ngp_kernel<F, 3>), dim3(blocks), dim3(256), 0, ctx->stream, p, payload, np, lcell, nsz, N, x0, nx, grid); break;
-    case 4: hipLaunchKernelGGL((deposit_ngp_kernel<F, 4>), dim3(blocks), dim3(256), 0, ctx->stream, p, payload, np, lcell, nsz, N, x0, nx, grid); break;
-    default: return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "deposit: C=%d channels (supported: 1,3,4)", C);
+  const Bricks b = make_bricks(N, x0, nx, C);
+  const DepLayout l = dep_layout(np, C, b);
+  char* work = reinterpret_cast<char*>(work_v);
+  unsigned* count = reinterpret_cast<unsigned*>(work + l.count);
+  unsigned* fill = reinterpret_cast<unsigned*>(work + l.fill);
+  unsigned* start = reinterpret_cast<unsigned*>(work + l.start);
+  unsigned* tiles = reinterpret_cast<unsigned*>(work + l.tiles);
+  unsigned* records = reinterpret_cast<unsigned*>(work + l.records);
+  // count and fill are adjacent: one memset
+  VPS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, l.start - l.count, ctx->stream));
+  const unsigned pblocks = (unsigned)((np + 255) / 256);
+  const float vol = (float)((Lbox / (double)N) * (Lbox / (double)N) * (Lbox / (double)N));
+  {
+    vps_launch_timer tm(ctx, VPS_K_DEPOSIT);
+    if (np > 0)
+      hipLaunchKernelGGL(brick_count_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np,
+                         lcell, nsz, b, count);
+    launch_exclusive_scan(ctx->stream, count, l.nbricks, tiles, start);
+    if (np > 0)
+      hipLaunchKernelGGL((brick_scatter_kernel<F, C, RHOV>), dim3(pblocks), dim3(256), 0, ctx->stream, pos,
+                         payload, rho, (long long)np, lcell, nsz, b, start, fill, records);
   }
+  VPS_HIP_CHECK(ctx, hipGetLastError());
+  {
+    vps_launch_timer tm(ctx, VPS_K_ALGEBRA);
+    const size_t lds = (size_t)C * b.cells * sizeof(float);
+    hipLaunchKernelGGL((brick_accumulate_kernel<C, EPI>), dim3((unsigned)l.nbricks), dim3(256), lds, ctx->stream,
+                       records, start, b, quantity, flags, vol, grid);
+  }
+  VPS_HIP_CHECK(ctx, hipGetLastError());
+  return VPS_OK;
+}
+
+int check_deposit_args(vps_ctx* ctx, const char* who, int64_t np, int N, double Lbox, int x0, int nx) {
+  if (np < 0 || N < 1 || !(Lbox > 0)) return vps_fail(ctx, VPS_ERR_ARG, "%s: bad np/N/Lbox", who);
+  if (x0 < 0 || nx < 1 || x0 + nx > N) return vps_fail(ctx, VPS_ERR_ARG, "%s: slab [%d,%d) outside [0,%d)", who, x0, x0 + nx, N);
+  if ((np + 255) / 256 > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "%s: np too large for one launch", who);
+  if (np > 0xffffffffLL) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "%s: np exceeds 32-bit bucket offsets", who);
   return VPS_OK;
 }
 
@@ -196,19 +411,48 @@ int vps_cell_index(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, int64_t np
   return VPS_OK;
 }
 
+size_t vps_deposit_workspace_bytes(int64_t np, int C, int N, int nx) {
+  if (np < 0 || C < 1 || N < 1 || nx < 1) return 0;
+  const Bricks b = make_bricks(N, 0, nx, C);
+  return dep_layout(np, C, b).total;
+}
+
 int vps_deposit_ngp(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* payload_dev,
-                    int64_t np, int C, int N, double Lbox, int x0, int nx, float* grid_dev) {
+                    int64_t np, int C, int N, double Lbox, int x0, int nx, float* grid_dev,
+                    void* work_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (np < 0 || N < 1 || !(Lbox > 0)) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_ngp: bad np/N/Lbox");
-  if (x0 < 0 || nx < 1 || x0 + nx > N) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_ngp: slab [%d,%d) outside [0,%d)", x0, x0 + nx, N);
-  if (np == 0) return VPS_OK;
-  if (!pos_dev || !payload_dev || !grid_dev) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_ngp: null buffer");
-  if ((np + 255) / 256 > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_deposit_ngp: np too large for one launch");
-  int rc = pos_is_f64 ? deposit_dispatch<double>(ctx, pos_dev, payload_dev, np, C, N, Lbox, x0, nx, grid_dev)
-                      : deposit_dispatch<float>(ctx, pos_dev, payload_dev, np, C, N, Lbox, x0, nx, grid_dev);
+  int rc = check_deposit_args(ctx, "vps_deposit_ngp", np, N, Lbox, x0, nx);
   if (rc) return rc;
-  VPS_HIP_CHECK(ctx, hipGetLastError());
-  return VPS_OK;
+  if (!grid_dev || !work_dev || (np > 0 && (!pos_dev || !payload_dev)))
+    return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_ngp: null buffer");
+#define VPS_DEP(CC)                                                                                        \
+  (pos_is_f64 ? deposit_run<double, CC, false, EPI_RAW>(ctx, pos_dev, payload_dev, nullptr, np, N, Lbox, x0, \
+                                                        nx, 0, 0, grid_dev, work_dev)                       \
+              : deposit_run<float, CC, false, EPI_RAW>(ctx, pos_dev, payload_dev, nullptr, np, N, Lbox, x0,  \
+                                                       nx, 0, 0, grid_dev, work_dev))
+  switch (C) {
+    case 1: return VPS_DEP(1);
+    case 3: return VPS_DEP(3);
+    case 4: return VPS_DEP(4);
+    default: return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_deposit_ngp: C=%d channels (supported: 1,3,4)", C);
+  }
+#undef VPS_DEP
+}
+
+int vps_deposit_field(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
+                      const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx, int quantity,
+                      int flags, float* fields_dev, void* work_dev) {
+  if (!ctx) return VPS_ERR_ARG;
+  int rc = check_deposit_args(ctx, "vps_deposit_field", np, N, Lbox, x0, nx);
+  if (rc) return rc;
+  if (quantity < 0 || quantity > 3) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_field: quantity %d", quantity);
+  if (flags & VPS_FLAG_INPUT_IS_VM) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_field: VPS_FLAG_INPUT_IS_VM is meaningless here");
+  if (!fields_dev || !work_dev || (np > 0 && (!pos_dev || !vel_dev || !rho_dev)))
+    return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_field: null buffer");
+  return pos_is_f64 ? deposit_run<double, 4, true, EPI_ALGEBRA>(ctx, pos_dev, vel_dev, rho_dev, np, N, Lbox, x0,
+                                                               nx, quantity, flags, fields_dev, work_dev)
+                    : deposit_run<float, 4, true, EPI_ALGEBRA>(ctx, pos_dev, vel_dev, rho_dev, np, N, Lbox, x0,
+                                                              nx, quantity, flags, fields_dev, work_dev);
 }
 
 int vps_density_velocity_vector(vps_ctx* ctx, const float* vel_dev, const float* rho_dev, int64_t np,

@@ -16,6 +16,7 @@
 #include <cmath>
 
 #include "vps_internal.h"
+#include "scan.h"
 
 namespace {
 
@@ -94,86 +95,6 @@ __global__ void __launch_bounds__(256)
   const int cy = cell_coord((double)pos[i * 3 + 1], g.lo[1], g.inv_w[1], g.M);
   const int cz = cell_coord((double)pos[i * 3 + 2], g.lo[2], g.inv_w[2], g.M);
   atomicAdd(&count[((long long)cx * g.M + cy) * g.M + cz], 1u);
-}
-
-// exclusive scan of `count` into `start` (n+1 entries), three small kernels
-constexpr int SCAN_BLOCK = 256;
-constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
-
-__global__ void __launch_bounds__(SCAN_BLOCK)
-    scan_tile_sums(const unsigned* __restrict__ count, long long n, unsigned* __restrict__ tile_sum) {
-  __shared__ unsigned red[SCAN_BLOCK / 64];
-  const long long base = (long long)blockIdx.x * SCAN_TILE;
-  unsigned s = 0;
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    const long long i = base + (long long)k * SCAN_BLOCK + threadIdx.x;
-    if (i < n) s += count[i];
-  }
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned t = 0;
-    for (int k = 0; k < SCAN_BLOCK / 64; ++k) t += red[k];
-    tile_sum[blockIdx.x] = t;
-  }
-}
-
-__global__ void __launch_bounds__(1024) scan_tile_offsets(unsigned* __restrict__ tile_sum, long long ntiles) {
-  // single workgroup: serial-over-chunks exclusive scan of the tile sums, in place
-  __shared__ unsigned sh[1024];
-  __shared__ unsigned carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (long long base = 0; base < ntiles; base += 1024) {
-    const long long i = base + threadIdx.x;
-    const unsigned v = (i < ntiles) ? tile_sum[i] : 0u;
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      unsigned add = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0u;
-      __syncthreads();
-      sh[threadIdx.x] += add;
-      __syncthreads();
-    }
-    const unsigned incl = sh[threadIdx.x];
-    const unsigned c = carry;
-    if (i < ntiles) tile_sum[i] = c + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = c + incl;
-    __syncthreads();
-  }
-}
-
-__global__ void __launch_bounds__(SCAN_BLOCK)
-    scan_apply(const unsigned* __restrict__ count, long long n, const unsigned* __restrict__ tile_off,
-               unsigned* __restrict__ start) {
-  // each thread owns SCAN_ITEMS consecutive counts
-  __shared__ unsigned sh[SCAN_BLOCK];
-  const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-  unsigned v[SCAN_ITEMS];
-  unsigned s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    v[k] = (base + k < n) ? count[base + k] : 0u;
-    s += v[k];
-  }
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
-    unsigned add = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0u;
-    __syncthreads();
-    sh[threadIdx.x] += add;
-    __syncthreads();
-  }
-  unsigned run = tile_off[blockIdx.x] + sh[threadIdx.x] - s;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    if (base + k < n) start[base + k] = run;
-    run += v[k];
-  }
-  if (base <= n - 1 && n - 1 < base + SCAN_ITEMS) start[n] = run;  // total
 }
 
 template <typename F>
@@ -343,9 +264,7 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
   {
     vps_launch_timer tm(ctx, VPS_K_NN_BUILD);
     hipLaunchKernelGGL(nn_count_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np, g, count);
-    hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)l.ntiles), dim3(SCAN_BLOCK), 0, ctx->stream, count, l.ncell, tiles);
-    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(1024), 0, ctx->stream, tiles, l.ntiles);
-    hipLaunchKernelGGL(scan_apply, dim3((unsigned)l.ntiles), dim3(SCAN_BLOCK), 0, ctx->stream, count, l.ncell, tiles, start);
+    launch_exclusive_scan(ctx->stream, count, l.ncell, tiles, start);
     hipLaunchKernelGGL(nn_fill_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np, g, start, fill, spos, sidx);
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());

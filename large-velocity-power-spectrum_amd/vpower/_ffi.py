@@ -40,8 +40,11 @@ SYMBOLS = (
     ("vps_timing_get", C.c_int, (_vp, C.c_int, C.POINTER(_i64), _dp)),
     ("vps_timing_list", C.c_int, (_vp, C.c_int, _dp, _i64, C.POINTER(_i64))),
     ("vps_cell_index", C.c_int, (_vp, _vp, C.c_int, _i64, C.c_int, C.c_double, _vp)),
+    ("vps_deposit_workspace_bytes", C.c_size_t, (_i64, C.c_int, C.c_int, C.c_int)),
     ("vps_deposit_ngp", C.c_int, (_vp, _vp, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_double,
-                                  C.c_int, C.c_int, _vp)),
+                                  C.c_int, C.c_int, _vp, _vp)),
+    ("vps_deposit_field", C.c_int, (_vp, _vp, C.c_int, _vp, _vp, _i64, C.c_int, C.c_double, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, _vp, _vp)),
     ("vps_density_velocity_vector", C.c_int, (_vp, _vp, _vp, _i64, _vp)),
     ("vps_nn_workspace_bytes", C.c_size_t, (_i64, C.c_int)),
     ("vps_nn_resample", C.c_int, (_vp, _vp, C.c_int, _vp, _i64, C.c_int, _dp, C.c_int, _dp, C.c_int,

@@ -218,14 +218,28 @@ class HipKernels:
         return out
 
     def deposit(self, pos, payload, N, Lbox, x0, nx, out=None):
-        """payload [np, C] float32 -> grid [C, nx, N, N] float32 (zeroed here unless given)."""
+        """payload [np, C] float32 -> grid [C, nx, N, N] float32 (every cell written)."""
         self._stream()
         C_ = payload.shape[1]
         if out is None:
-            out = self.zeros((C_, nx, N, N), torch.float32)
+            out = self.empty((C_, nx, N, N), torch.float32)
+        work = self.workspace("deposit", self.lib.vps_deposit_workspace_bytes(pos.shape[0], C_, N, nx))
         self._chk(self.lib.vps_deposit_ngp(self.ctx, self._ptr(pos), self._pos_kind(pos),
                                            self._ptr(payload, torch.float32), pos.shape[0], C_, N,
-                                           float(Lbox), x0, nx, self._ptr(out, torch.float32)))
+                                           float(Lbox), x0, nx, self._ptr(out, torch.float32), self._ptr(work)))
+        return out
+
+    def deposit_field(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, out=None):
+        """Fused deposit of [rho v, rho] + field algebra -> [ncomp, nx, N, N] float32."""
+        self._stream()
+        ncomp = {VELOCITY: 3, MOMENTUM: 3, ENERGY: 1, VM: 4}[quantity]
+        if out is None:
+            out = self.empty((ncomp, nx, N, N), torch.float32)
+        work = self.workspace("deposit", self.lib.vps_deposit_workspace_bytes(pos.shape[0], 4, N, nx))
+        self._chk(self.lib.vps_deposit_field(self.ctx, self._ptr(pos), self._pos_kind(pos),
+                                             self._ptr(vel, torch.float32), self._ptr(rho, torch.float32),
+                                             pos.shape[0], N, float(Lbox), x0, nx, quantity, flags,
+                                             self._ptr(out, torch.float32), self._ptr(work)))
         return out
 
     def nn_resample(self, pos, payload, axes, x0, nx, want_index=False, out=None):

@@ -141,10 +141,10 @@ class GasParticles:
         density_velocity_vector (interp.py:996-1015), then v=rho v/rho with empty cells set
         to 0 (the rule of interp.py:329-331) and m=rho*Lcell^3 (interp.py:272-273)."""
         k = _kernels()
-        Lcell = self.Lbox / Nsize
-        grid = k.deposit(_pos_tensor(k, self.pos), self._device_payload(k), Nsize, self.Lbox, 0, Nsize)
-        k.field_algebra(grid, _dev.VM, 0, Lcell)
-        return BoxField._from_device(grid, Lcell)
+        vel = k.to_device(np.asarray(self.v), torch.float32)
+        rho = k.to_device(np.asarray(self.density), torch.float32)
+        grid = k.deposit_field(_pos_tensor(k, self.pos), vel, rho, Nsize, self.Lbox, 0, Nsize, _dev.VM)
+        return BoxField._from_device(grid, self.Lbox / Nsize)
 
     def total_mass(self) -> float:
         return np.sum(self.mass)

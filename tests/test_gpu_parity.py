@@ -325,6 +325,10 @@ def test_config2_properties(K):
     assert np.allclose(tot[:3], ref, rtol=1e-6, atol=1e-3 * np.sqrt(Np))
     assert abs(tot[3] - dens.astype(np.float64).sum()) < 1e-6 * Np
     K.field_algebra(grid, device.VELOCITY, 0, L / N)
+    # the fused deposit+algebra path gives the same three velocity fields
+    fused = K.deposit_field(dpos, K.to_device(vel), K.to_device(dens), N, L, 0, N, device.VELOCITY)
+    assert torch.allclose(fused, grid[:3], rtol=1e-5, atol=1e-6)
+    del fused
     pipe = device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False))
     fields = [grid[0], grid[1], grid[2]]
     tab = pipe.finish(*pipe.accumulate(fields))
