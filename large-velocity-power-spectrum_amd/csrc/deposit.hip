@@ -9,7 +9,8 @@
 //                bx*by*bz block of cells whose C float channels fit a 64 KiB LDS tile);
 //   2. scan    : exclusive prefix sum of the brick counts;
 //   3. scatter : second pass, each particle's record {cell-in-brick, payload[C]} is
-//                written into its brick's contiguous bucket;
+//                written into its brick's contiguous bucket (slot = start + rank, the
+//                rank being what the counting atomic of pass 1 returned);
 //   4. bricks  : one workgroup per brick adds its bucket into an LDS tile with LDS
 //                float atomics and then streams the WHOLE tile out with full-width
 //                coalesced stores (rows of bz cells), applying the field algebra
@@ -89,6 +90,7 @@ struct Bricks {
   int bx, by, bz;       // brick extent in cells
   int nbx, nby, nbz;    // bricks per axis of the slab
   int cells;            // bx*by*bz
+  int pow2, sy, sz;     // by, bz powers of two: log2(by), log2(bz)
 };
 
 // brick id and cell-in-brick of a particle, or false when it is outside the slab
@@ -106,28 +108,38 @@ __device__ __forceinline__ bool locate(const F* __restrict__ pos, long long i, F
   return true;
 }
 
+// Pass 1: one returning atomic per particle gives both the brick histogram and the
+// particle's rank inside its brick.  key = brick * cells + cell-in-brick (0xffff.. = outside).
 template <typename F>
 __global__ void __launch_bounds__(256)
-    brick_count_kernel(const F* __restrict__ pos, long long np, F lcell, F nsize, Bricks b,
-                       unsigned* __restrict__ count) {
+    brick_rank_kernel(const F* __restrict__ pos, long long np, F lcell, F nsize, Bricks b,
+                      unsigned* __restrict__ count, unsigned long long* __restrict__ keys,
+                      unsigned* __restrict__ ranks) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= np) return;
   unsigned brick, loc;
-  if (locate<F>(pos, i, lcell, nsize, b, brick, loc)) atomicAdd(&count[brick], 1u);
+  if (locate<F>(pos, i, lcell, nsize, b, brick, loc)) {
+    ranks[i] = atomicAdd(&count[brick], 1u);
+    keys[i] = (unsigned long long)brick * (unsigned)b.cells + loc;
+  } else {
+    keys[i] = ~0ull;
+  }
 }
 
-// record = {loc, payload[C]} as (C+1) 32-bit words.  RHOV: payload is built from velocity
-// and density on the fly ([rho vx, rho vy, rho vz, rho], interp.py:199-213).
-template <typename F, int C, bool RHOV>
+// Pass 2 (after the scan): record = {loc, payload[C]} as (C+1) 32-bit words goes to slot
+// start[brick] + rank.  RHOV: payload is built from velocity and density on the fly
+// ([rho vx, rho vy, rho vz, rho], interp.py:199-213).
+template <int C, bool RHOV>
 __global__ void __launch_bounds__(256)
-    brick_scatter_kernel(const F* __restrict__ pos, const float* __restrict__ payload,
-                         const float* __restrict__ rho, long long np, F lcell, F nsize, Bricks b,
-                         const unsigned* __restrict__ start, unsigned* __restrict__ fill,
+    brick_scatter_kernel(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ ranks,
+                         const float* __restrict__ payload, const float* __restrict__ rho, long long np,
+                         unsigned cells, const unsigned* __restrict__ start,
                          unsigned* __restrict__ records) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= np) return;
-  unsigned brick, loc;
-  if (!locate<F>(pos, i, lcell, nsize, b, brick, loc)) return;
+  const unsigned long long key = keys[i];
+  if (key == ~0ull) return;
+  const unsigned brick = (unsigned)(key / cells), loc = (unsigned)(key % cells);
   float val[C];
   if constexpr (RHOV) {
     static_assert(C == 4, "rho*v payload has four channels");
@@ -143,8 +155,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int c = 0; c < C; ++c) val[c] = payload[i * C + c];
   }
-  const unsigned slot = start[brick] + atomicAdd(&fill[brick], 1u);
-  unsigned* rec = records + (size_t)slot * (C + 1);
+  unsigned* rec = records + (size_t)(start[brick] + ranks[i]) * (C + 1);
   rec[0] = loc;
 #pragma unroll
   for (int c = 0; c < C; ++c) rec[1 + c] = __float_as_uint(val[c]);
@@ -162,9 +173,12 @@ __device__ __forceinline__ void algebra_cell(float a, float b, float c, float rh
   if (flags & VPS_FLAG_INPUT_IS_VM) {
     vx = a; vy = b; vz = c; m = rho;
   } else {
-    vx = rho != 0.f ? a / rho : 0.f;
-    vy = rho != 0.f ? b / rho : 0.f;
-    vz = rho != 0.f ? c / rho : 0.f;
+    // one reciprocal per cell (about 1 ulp; the result is compared at 2e-5 with a float64
+    // reference) instead of three IEEE divisions
+    const float inv = rho != 0.f ? __frcp_rn(rho) : 0.f;
+    vx = a * inv;
+    vy = b * inv;
+    vz = c * inv;
     m = rho * vol;
   }
   if (quantity == VPS_MOMENTUM) {
@@ -185,74 +199,119 @@ __host__ __device__ inline int quantity_channels(int quantity) {
   return quantity == VPS_ENERGY ? 1 : (quantity == VPS_VM ? 4 : 3);
 }
 
-template <int C, int EPI>
+// QUANT is the (compile-time) quantity of the algebra epilogue; NOUT its channel count
+template <int C, int EPI, int QUANT>
 __global__ void __launch_bounds__(256)
     brick_accumulate_kernel(const unsigned* __restrict__ records, const unsigned* __restrict__ start,
-                            Bricks b, int quantity, int flags, float vol, float* __restrict__ grid) {
+                            Bricks b, long long nbricks, int flags, float vol,
+                            float* __restrict__ grid) {
+  constexpr int quantity = QUANT;
+  constexpr int NOUT = (EPI == EPI_RAW) ? C : (QUANT == VPS_ENERGY ? 1 : (QUANT == VPS_VM ? 4 : 3));
+  // Persistent workgroups walk the bricks: the streaming stores of one brick stay in flight
+  // while the next bucket is being accumulated, and the tile is re-zeroed as it is read.
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* tile = reinterpret_cast<float*>(smem_raw);  // [C][cells]
   const int cells = b.cells;
-  for (int i = threadIdx.x; i < C * cells; i += blockDim.x) tile[i] = 0.f;
-  __syncthreads();
-  const unsigned brick = blockIdx.x;
-  const unsigned s = start[brick], e = start[brick + 1];
-  for (unsigned j = s + threadIdx.x; j < e; j += blockDim.x) {
-    const unsigned* rec = records + (size_t)j * (C + 1);
-    const unsigned loc = rec[0];
-#pragma unroll
-    for (int c = 0; c < C; ++c) atomicAdd(&tile[c * cells + loc], __uint_as_float(rec[1 + c]));
+  const bool vec4 = ((b.bz & 3) == 0) && ((b.N & 3) == 0);
+  if ((cells & 3) == 0) {
+    for (int i = threadIdx.x; i < C * cells / 4; i += blockDim.x)
+      reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    for (int i = threadIdx.x; i < C * cells; i += blockDim.x) tile[i] = 0.f;
+  }
+  const long long plane = (long long)b.nx * b.N * b.N;
+  long long brick = blockIdx.x;
+  unsigned s = 0, e = 0;
+  if (brick < nbricks) {
+    s = start[brick];
+    e = start[brick + 1];
   }
   __syncthreads();
-  // stream the tile out: rows of bz cells are contiguous in the grid
-  const int iz = brick % b.nbz, iy = (brick / b.nbz) % b.nby, ix = brick / (b.nbz * b.nby);
-  const int gx0 = ix * b.bx, gy0 = iy * b.by, gz0 = iz * b.bz;
-  const long long plane = (long long)b.nx * b.N * b.N;
-  const int nout = (EPI == EPI_RAW) ? C : quantity_channels(quantity);
-  const bool vec4 = ((b.bz & 3) == 0) && ((b.N & 3) == 0);
-  if (vec4) {
-    const int q4 = cells / 4;
-    for (int i = threadIdx.x; i < q4; i += blockDim.x) {
-      const int loc = i * 4;
-      const int lz = loc % b.bz, ly = (loc / b.bz) % b.by, lx = loc / (b.bz * b.by);
-      const int gx = gx0 + lx, gy = gy0 + ly, gz = gz0 + lz;
-      if (gx >= b.nx || gy >= b.N || gz >= b.N) continue;   // partial bricks at the slab edge
-      const long long cell = ((long long)gx * b.N + gy) * b.N + gz;
-      float4 ch[C];
+  for (; brick < nbricks; brick += gridDim.x) {
+    for (unsigned j = s + threadIdx.x; j < e; j += blockDim.x) {
+      const unsigned* rec = records + (size_t)j * (C + 1);
+      const unsigned loc = rec[0];
 #pragma unroll
-      for (int c = 0; c < C; ++c) ch[c] = *reinterpret_cast<const float4*>(tile + c * cells + loc);
-      if constexpr (EPI == EPI_RAW) {
+      for (int c = 0; c < C; ++c) atomicAdd(&tile[c * cells + loc], __uint_as_float(rec[1 + c]));
+    }
+    // bucket bounds of the next brick: in flight during the stream-out below
+    const long long nb = brick + gridDim.x;
+    if (nb < nbricks) {
+      s = start[nb];
+      e = start[nb + 1];
+    }
+    __syncthreads();
+    // stream the tile out: rows of bz cells are contiguous in the grid
+    const int iz = (int)(brick % b.nbz), iy = (int)((brick / b.nbz) % b.nby);
+    const int ix = (int)(brick / ((long long)b.nbz * b.nby));
+    const int gx0 = ix * b.bx, gy0 = iy * b.by, gz0 = iz * b.bz;
+    if (vec4) {
+      const int q4 = cells / 4;
+      for (int i = threadIdx.x; i < q4; i += blockDim.x) {
+        const int loc = i * 4;
+        int lz, ly, lx;
+        if (b.pow2) {
+          lz = loc & (b.bz - 1);
+          ly = (loc >> b.sz) & (b.by - 1);
+          lx = loc >> (b.sz + b.sy);
+        } else {
+          lz = loc % b.bz; ly = (loc / b.bz) % b.by; lx = loc / (b.bz * b.by);
+        }
+        const int gx = gx0 + lx, gy = gy0 + ly, gz = gz0 + lz;
+        const bool inside = gx < b.nx && gy < b.N && gz < b.N;   // partial bricks at the slab edge
+        const long long cell = ((long long)gx * b.N + gy) * b.N + gz;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (EPI == EPI_RAW) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) *reinterpret_cast<float4*>(grid + c * plane + cell) = ch[c];
-      } else {
-        float4 o[4];
-        float r[4];
-        algebra_cell(ch[0].x, ch[1].x, ch[2].x, ch[3].x, quantity, flags, vol, r);
-        o[0].x = r[0]; o[1].x = r[1]; o[2].x = r[2]; o[3].x = r[3];
-        algebra_cell(ch[0].y, ch[1].y, ch[2].y, ch[3].y, quantity, flags, vol, r);
-        o[0].y = r[0]; o[1].y = r[1]; o[2].y = r[2]; o[3].y = r[3];
-        algebra_cell(ch[0].z, ch[1].z, ch[2].z, ch[3].z, quantity, flags, vol, r);
-        o[0].z = r[0]; o[1].z = r[1]; o[2].z = r[2]; o[3].z = r[3];
-        algebra_cell(ch[0].w, ch[1].w, ch[2].w, ch[3].w, quantity, flags, vol, r);
-        o[0].w = r[0]; o[1].w = r[1]; o[2].w = r[2]; o[3].w = r[3];
-        for (int c = 0; c < nout; ++c) *reinterpret_cast<float4*>(grid + c * plane + cell) = o[c];
+          for (int c = 0; c < C; ++c) {
+            float4* t = reinterpret_cast<float4*>(tile + c * cells + loc);
+            const float4 val = *t;
+            *t = zero4;
+            if (inside) *reinterpret_cast<float4*>(grid + c * plane + cell) = val;
+          }
+        } else {
+          float4* t0 = reinterpret_cast<float4*>(tile + loc);
+          float4* t1 = reinterpret_cast<float4*>(tile + cells + loc);
+          float4* t2 = reinterpret_cast<float4*>(tile + 2 * cells + loc);
+          float4* t3 = reinterpret_cast<float4*>(tile + 3 * cells + loc);
+          const float4 c0 = *t0, c1 = *t1, c2 = *t2, c3 = *t3;
+          *t0 = zero4; *t1 = zero4; *t2 = zero4; *t3 = zero4;
+          if (inside) {
+            float rx[4], ry[4], rz[4], rw[4];
+            algebra_cell(c0.x, c1.x, c2.x, c3.x, quantity, flags, vol, rx);
+            algebra_cell(c0.y, c1.y, c2.y, c3.y, quantity, flags, vol, ry);
+            algebra_cell(c0.z, c1.z, c2.z, c3.z, quantity, flags, vol, rz);
+            algebra_cell(c0.w, c1.w, c2.w, c3.w, quantity, flags, vol, rw);
+#pragma unroll
+            for (int c = 0; c < NOUT; ++c)
+              *reinterpret_cast<float4*>(grid + c * plane + cell) = make_float4(rx[c], ry[c], rz[c], rw[c]);
+          }
+        }
+      }
+    } else {
+      for (int loc = threadIdx.x; loc < cells; loc += blockDim.x) {
+        const int lz = loc % b.bz, ly = (loc / b.bz) % b.by, lx = loc / (b.bz * b.by);
+        const int gx = gx0 + lx, gy = gy0 + ly, gz = gz0 + lz;
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          v[c] = tile[c * cells + loc];
+          tile[c * cells + loc] = 0.f;
+        }
+        if (gx >= b.nx || gy >= b.N || gz >= b.N) continue;
+        const long long cell = ((long long)gx * b.N + gy) * b.N + gz;
+        if constexpr (EPI == EPI_RAW) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) grid[c * plane + cell] = v[c];
+        } else {
+          float r[4];
+          algebra_cell(v[0], v[1], v[2], v[3], quantity, flags, vol, r);
+#pragma unroll
+          for (int c = 0; c < NOUT; ++c) grid[c * plane + cell] = r[c];
+        }
       }
     }
-  } else {
-    for (int loc = threadIdx.x; loc < cells; loc += blockDim.x) {
-      const int lz = loc % b.bz, ly = (loc / b.bz) % b.by, lx = loc / (b.bz * b.by);
-      const int gx = gx0 + lx, gy = gy0 + ly, gz = gz0 + lz;
-      if (gx >= b.nx || gy >= b.N || gz >= b.N) continue;
-      const long long cell = ((long long)gx * b.N + gy) * b.N + gz;
-      if constexpr (EPI == EPI_RAW) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) grid[c * plane + cell] = tile[c * cells + loc];
-      } else {
-        float r[4];
-        algebra_cell(tile[loc], tile[cells + loc], tile[2 * cells + loc], tile[3 * cells + loc], quantity,
-                     flags, vol, r);
-        for (int c = 0; c < nout; ++c) grid[c * plane + cell] = r[c];
-      }
-    }
+    __syncthreads();   // tile is all zero again
   }
 }
 
@@ -266,13 +325,15 @@ __global__ void __launch_bounds__(256)
   float4 b = *reinterpret_cast<float4*>(ch + ncell + i0);
   float4 c = *reinterpret_cast<float4*>(ch + 2 * ncell + i0);
   float4 m = *reinterpret_cast<float4*>(ch + 3 * ncell + i0);
-  float* pa = &a.x; float* pb = &b.x; float* pc = &c.x; float* pm = &m.x;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float r[4];
-    algebra_cell(pa[j], pb[j], pc[j], pm[j], quantity, flags, vol, r);
-    pa[j] = r[0]; pb[j] = r[1]; pc[j] = r[2]; pm[j] = r[3];
-  }
+  float r[4];
+  algebra_cell(a.x, b.x, c.x, m.x, quantity, flags, vol, r);
+  a.x = r[0]; b.x = r[1]; c.x = r[2]; m.x = r[3];
+  algebra_cell(a.y, b.y, c.y, m.y, quantity, flags, vol, r);
+  a.y = r[0]; b.y = r[1]; c.y = r[2]; m.y = r[3];
+  algebra_cell(a.z, b.z, c.z, m.z, quantity, flags, vol, r);
+  a.z = r[0]; b.z = r[1]; c.z = r[2]; m.z = r[3];
+  algebra_cell(a.w, b.w, c.w, m.w, quantity, flags, vol, r);
+  a.w = r[0]; b.w = r[1]; c.w = r[2]; m.w = r[3];
   *reinterpret_cast<float4*>(ch + i0) = a;
   if (quantity != VPS_ENERGY) {
     *reinterpret_cast<float4*>(ch + ncell + i0) = b;
@@ -292,6 +353,10 @@ __global__ void __launch_bounds__(256)
       make_float4(vel[i * 3 + 0] * r, vel[i * 3 + 1] * r, vel[i * 3 + 2] * r, r);
 }
 
+// LDS tile of one brick: 32 KiB -> four bricks resident per CU, enough workgroups in
+// flight to hide the bucket-read -> LDS-add -> stream-out dependency chain of each one
+#define VPS_BRICK_LDS_BYTES (32 * 1024)
+
 int pow2_floor(int v) {
   int p = 1;
   while (p * 2 <= v) p *= 2;
@@ -301,7 +366,7 @@ int pow2_floor(int v) {
 Bricks make_bricks(int N, int x0, int nx, int C) {
   Bricks b;
   b.N = N; b.x0 = x0; b.nx = nx;
-  const int max_cells = (64 * 1024) / (4 * C);        // 64 KiB LDS tile
+  const int max_cells = (VPS_BRICK_LDS_BYTES) / (4 * C);
   b.bz = N < 64 ? N : 64;                              // up to 256-byte rows
   if (b.bz > max_cells) b.bz = max_cells;
   int rest = max_cells / b.bz;
@@ -314,11 +379,15 @@ Bricks make_bricks(int N, int x0, int nx, int C) {
   b.nby = (N + b.by - 1) / b.by;
   b.nbz = (N + b.bz - 1) / b.bz;
   b.cells = b.bx * b.by * b.bz;
+  b.pow2 = ((b.by & (b.by - 1)) == 0) && ((b.bz & (b.bz - 1)) == 0);
+  b.sy = b.sz = 0;
+  while ((1 << b.sy) < b.by) ++b.sy;
+  while ((1 << b.sz) < b.bz) ++b.sz;
   return b;
 }
 
 struct DepLayout {
-  size_t count, fill, start, tiles, records, total;
+  size_t count, start, tiles, keys, ranks, records, total;
   long long nbricks;
 };
 
@@ -328,9 +397,10 @@ DepLayout dep_layout(int64_t np, int C, const Bricks& b) {
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t off = 0;
   l.count = off;   off = align(off + sizeof(unsigned) * l.nbricks);
-  l.fill = off;    off = align(off + sizeof(unsigned) * l.nbricks);
   l.start = off;   off = align(off + sizeof(unsigned) * (l.nbricks + 1));
   l.tiles = off;   off = align(off + sizeof(unsigned) * (scan_tiles(l.nbricks) + 1));
+  l.keys = off;    off = align(off + (size_t)np * sizeof(unsigned long long));
+  l.ranks = off;   off = align(off + (size_t)np * sizeof(unsigned));
   l.records = off; off = align(off + (size_t)np * (C + 1) * sizeof(unsigned));
   l.total = off;
   return l;
@@ -348,30 +418,41 @@ int deposit_run(vps_ctx* ctx, const void* pos_v, const float* payload, const flo
   const DepLayout l = dep_layout(np, C, b);
   char* work = reinterpret_cast<char*>(work_v);
   unsigned* count = reinterpret_cast<unsigned*>(work + l.count);
-  unsigned* fill = reinterpret_cast<unsigned*>(work + l.fill);
   unsigned* start = reinterpret_cast<unsigned*>(work + l.start);
   unsigned* tiles = reinterpret_cast<unsigned*>(work + l.tiles);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(work + l.keys);
+  unsigned* ranks = reinterpret_cast<unsigned*>(work + l.ranks);
   unsigned* records = reinterpret_cast<unsigned*>(work + l.records);
-  // count and fill are adjacent: one memset
-  VPS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, l.start - l.count, ctx->stream));
+  VPS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, sizeof(unsigned) * l.nbricks, ctx->stream));
   const unsigned pblocks = (unsigned)((np + 255) / 256);
   const float vol = (float)((Lbox / (double)N) * (Lbox / (double)N) * (Lbox / (double)N));
   {
     vps_launch_timer tm(ctx, VPS_K_DEPOSIT);
     if (np > 0)
-      hipLaunchKernelGGL(brick_count_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np,
-                         lcell, nsz, b, count);
+      hipLaunchKernelGGL(brick_rank_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np,
+                         lcell, nsz, b, count, keys, ranks);
     launch_exclusive_scan(ctx->stream, count, l.nbricks, tiles, start);
     if (np > 0)
-      hipLaunchKernelGGL((brick_scatter_kernel<F, C, RHOV>), dim3(pblocks), dim3(256), 0, ctx->stream, pos,
-                         payload, rho, (long long)np, lcell, nsz, b, start, fill, records);
+      hipLaunchKernelGGL((brick_scatter_kernel<C, RHOV>), dim3(pblocks), dim3(256), 0, ctx->stream, keys, ranks,
+                         payload, rho, (long long)np, (unsigned)b.cells, start, records);
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
   {
     vps_launch_timer tm(ctx, VPS_K_ALGEBRA);
     const size_t lds = (size_t)C * b.cells * sizeof(float);
-    hipLaunchKernelGGL((brick_accumulate_kernel<C, EPI>), dim3((unsigned)l.nbricks), dim3(256), lds, ctx->stream,
-                       records, start, b, quantity, flags, vol, grid);
+    long long per_cu = (long long)(ctx->lds_per_cu / (lds ? lds : 1));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    long long grid_wg = (long long)ctx->num_cu * per_cu;
+    if (grid_wg > l.nbricks) grid_wg = l.nbricks;
+#define VPS_BRICK(Q)                                                                                      \
+  hipLaunchKernelGGL((brick_accumulate_kernel<C, EPI, Q>), dim3((unsigned)grid_wg), dim3(256), lds, ctx->stream, \
+                     records, start, b, l.nbricks, flags, vol, grid)
+    if (EPI == EPI_RAW || quantity == VPS_VELOCITY) VPS_BRICK(VPS_VELOCITY);
+    else if (quantity == VPS_MOMENTUM) VPS_BRICK(VPS_MOMENTUM);
+    else if (quantity == VPS_ENERGY) VPS_BRICK(VPS_ENERGY);
+    else VPS_BRICK(VPS_VM);
+#undef VPS_BRICK
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
   return VPS_OK;
