@@ -177,6 +177,7 @@ int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev,
  *         (interp.py:1440-1482) / pair_power+hist_sample (parallel_optimized.py:145-190).
  * mode 3: as mode 0 but shell sums only (nsample_dev untouched): the counts depend on the
  *         mode lattice alone, so a vector spectrum counts once, on its first component.
+ * mode 4: transform and discard (a timing aid: the pass without its epilogue).
  * mode 1: write the transformed lines to out_dev[i][kx] (complex64, contiguous).
  * mode 2: out_dev[i][kx] (float32) += |F|^2, no binning (component sums of
  *         _vector_power, interp.py:1386).                                           */

@@ -1,5 +1,6 @@
 // Context, memory, timing and binning-table entry points of the C ABI.
 #include <cstdarg>
+#include <cstdlib>
 
 #include "vps_internal.h"
 
@@ -209,8 +210,13 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
   for (int i = 0; i < nbins; ++i)
     if (!(thr_host[i] <= thr_host[i + 1]))
       return vps_fail(ctx, VPS_ERR_ARG, "vps_set_binning: thresholds must be non-decreasing (i=%d)", i);
+  // mirrored-kx fast path of the x pass: k2[N-i] == k2[i] and k2 non-decreasing on [0, N/2]
+  // (VPS_NO_FAST_BINNING=1 forces the general path, for tests)
+  bool fast = (N % 2 == 0) && !getenv("VPS_NO_FAST_BINNING");
+  for (int i = 1; fast && i < N / 2; ++i) fast = (k2_axis_host[N - i] == k2_axis_host[i]);
+  for (int i = 0; fast && i < N / 2; ++i) fast = (k2_axis_host[i] <= k2_axis_host[i + 1]);
   // unchanged tables (the usual case inside a loop over fields/steps): nothing to do
-  if (ctx->d_k2 && ctx->bin_N == N && ctx->nbins == nbins && ctx->edge0 == edge0 &&
+  if (ctx->d_k2 && ctx->bin_fast == fast && ctx->bin_N == N && ctx->nbins == nbins && ctx->edge0 == edge0 &&
       ctx->inv_spacing == inv_spacing && (int)ctx->h_k2.size() == N &&
       memcmp(ctx->h_k2.data(), k2_axis_host, sizeof(double) * N) == 0 &&
       memcmp(ctx->h_thr.data(), thr_host, sizeof(double) * (nbins + 1)) == 0)
@@ -226,6 +232,7 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
   VPS_HIP_CHECK(ctx, hipMemcpy(ctx->d_thr, thr_host, sizeof(double) * (nbins + 1), hipMemcpyHostToDevice));
   ctx->h_k2.assign(k2_axis_host, k2_axis_host + N);
   ctx->h_thr.assign(thr_host, thr_host + nbins + 1);
+  ctx->bin_fast = fast;
   ctx->bin_N = N;
   ctx->nbins = nbins;
   ctx->edge0 = edge0;

@@ -367,14 +367,19 @@ struct XParams {
   unsigned long long* nsample;
 };
 
-template <int NC, int T, int MODE, bool SEG, bool COUNT>
+// FAST (MODE 0 only): the k^2 table is symmetric (k2[N-i] == k2[i]) and non-decreasing on
+// [0, N/2] -- true for 2 pi fftfreq -- so kx and -kx share one s and one shell: a lane
+// then walks RL/2 values of |kx|, adds the two mirrored |F|^2 and issues one LDS atomic
+// per |kx|, with no per-element branches (the host checks the table, vps_set_binning).
+template <int NC, int T, int MODE, bool SEG, bool COUNT, bool FAST>
 __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p) {
   typedef PlanInfo<NC> PI;
   constexpr int L = PI::L, RL = PI::RL, NT = T * L;
+  constexpr int H = RL / 2;   // |kx| values per lane on the FAST path
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  // carve: thr (double) | hsum (double) | tw | line buffers | hcnt
+  // carve: thr (double, nbins+2 with a +inf sentinel) | hsum (double) | tw | line buffers | hcnt
   double* thr = reinterpret_cast<double*>(smem_raw);
-  double* hsum = thr + (MODE == 0 ? (p.nbins + 1) : 0);
+  double* hsum = thr + (MODE == 0 ? (p.nbins + 2) : 0);
   cf* tw = reinterpret_cast<cf*>(hsum + (MODE == 0 ? p.nbins : 0));
   cf* buf = tw + ((PI::TW + 1) & ~1);
   unsigned* hcnt = reinterpret_cast<unsigned*>(buf + T * PI::PITCH);
@@ -384,16 +389,21 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   for (int i = tid; i < PI::TW; i += NT) tw[i] = p.tw_stage[i];
   // fl(kx*kx) of this lane's contiguous chunk of RL kx values, ordered by non-decreasing
   // |kx|: the chunks of the negative-frequency half (index >= NC/2) are walked backwards
-  double k2x[MODE == 0 ? RL : 1];
+  double k2x[MODE == 0 ? (FAST ? H : RL) : 1];
   const bool rev = (l * RL) >= NC / 2;
   if constexpr (MODE == 0) {
-    for (int i = tid; i <= p.nbins; i += NT) thr[i] = p.thr[i];
+    for (int i = tid; i <= p.nbins + 1; i += NT) thr[i] = (i <= p.nbins) ? p.thr[i] : INFINITY;
     for (int i = tid; i < p.nbins; i += NT) {
       hsum[i] = 0.0;
       if constexpr (COUNT) hcnt[i] = 0u;
     }
+    if constexpr (FAST) {
 #pragma unroll
-    for (int i = 0; i < RL; ++i) k2x[i] = p.k2[l * RL + (rev ? RL - 1 - i : i)];
+      for (int i = 0; i < H; ++i) k2x[i] = p.k2[l * H + i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < RL; ++i) k2x[i] = p.k2[l * RL + (rev ? RL - 1 - i : i)];
+    }
   }
   __syncthreads();
 
@@ -429,6 +439,10 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
 #pragma unroll
         for (int i = 0; i < RL; ++i) o[out_index<NC>(l, i)] = v[i];
       }
+    } else if constexpr (MODE == 4) {
+      // transform only (timing aid): keep the results alive without storing them
+#pragma unroll
+      for (int i = 0; i < RL; ++i) asm volatile("" ::"v"(v[i].x), "v"(v[i].y));
     } else if constexpr (MODE == 2) {
       if (live) {
         float* o = reinterpret_cast<float*>(p.out) + li * (long long)NC;
@@ -442,13 +456,62 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
       // atomic per run, and the lanes of a wave-instruction hit different bins.
       float* pw = reinterpret_cast<float*>(line);
       if constexpr (PI::R1 > 1) __syncthreads();  // last exchange fully consumed
+      constexpr int CH = FAST ? H : RL;              // chunk length; one pad word per chunk
 #pragma unroll
       for (int i = 0; i < RL; ++i) {
         const int k = out_index<NC>(l, i);
-        pw[k + k / RL] = v[i].x * v[i].x + v[i].y * v[i].y;   // one pad word per chunk
+        pw[k + k / CH] = v[i].x * v[i].x + v[i].y * v[i].y;
       }
       __syncthreads();
-      if (live) {
+      if constexpr (FAST) {
+        if (live) {
+          const long long g = p.line0 + li;
+          const int ky = (int)(g % p.N);
+          const int kz = p.kz0 + (int)(g / p.N);
+          const double k2y = p.k2[ky], k2z = p.k2[kz];
+          const unsigned w = (kz == 0 || 2 * kz == p.N) ? 1u : 2u;
+          const double wd = (double)w;
+          const float* mine = pw + l * (H + 1);                        // kx = l*H + i
+          const float* mirr = pw + (NC + NC / H - 1) - l * (H + 1);    // NC-kx for i >= 1 at mirr[-i]
+          double s = (k2x[0] + k2y) + k2z;
+          int cur = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
+          cur = min(max(cur, 0), p.nbins - 1);
+          while (cur > 0 && s < thr[cur]) --cur;
+          while (cur < p.nbins - 1 && s >= thr[cur + 1]) ++cur;
+          if (s < thr[cur]) cur = -1;
+          else if (s >= thr[cur + 1]) cur = p.nbins;
+          double nxt = thr[cur + 1];
+#pragma unroll
+          for (int i = 0; i < H; ++i) {
+            float pv = mine[i];
+            unsigned c = 1u;
+            if (i > 0) {
+              // s = (kx*kx + ky*ky) + kz*kz with numpy's rounding (the table holds fl(k*k))
+              s = (k2x[i] + k2y) + k2z;
+              cur += (s >= nxt) ? 1 : 0;
+              nxt = thr[cur + 1];
+              while (s >= nxt) nxt = thr[++cur + 1];   // bins narrower than one kx step only
+              pv += mirr[-i];
+              c = 2u;
+            } else if (l > 0) {
+              pv += mirr[1];
+              c = 2u;
+            }
+            if ((unsigned)cur < (unsigned)p.nbins) {
+              atomicAdd(&hsum[cur], (double)pv * wd);
+              if constexpr (COUNT) atomicAdd(&hcnt[cur], c * w);
+            }
+          }
+          if (l == L - 1) {   // the unpaired kx = NC/2 mode
+            s = (p.k2[NC / 2] + k2y) + k2z;
+            while (s >= nxt) nxt = thr[++cur + 1];
+            if ((unsigned)cur < (unsigned)p.nbins) {
+              atomicAdd(&hsum[cur], (double)pw[NC / 2 + L] * wd);
+              if constexpr (COUNT) atomicAdd(&hcnt[cur], w);
+            }
+          }
+        }
+      } else if (live) {
         const long long g = p.line0 + li;
         const int ky = (int)(g % p.N);
         const int kz = p.kz0 + (int)(g / p.N);
@@ -558,14 +621,17 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
 }
 
 template <int NC, int MODE, bool COUNT = false>
-int launch_x(vps_ctx* ctx, const XParams& p) {
+int launch_x(vps_ctx* ctx, const XParams& p, bool fast = false) {
   constexpr int T = xpass_T<NC>();
   typedef PlanInfo<NC> PI;
   size_t lds = (((PI::TW + 1) & ~1) + (size_t)T * PI::PITCH) * sizeof(cf);
-  if (MODE == 0) lds += (size_t)(2 * p.nbins + 1) * sizeof(double) + (COUNT ? (size_t)p.nbins * sizeof(unsigned) : 0);
+  if (MODE == 0) lds += (size_t)(2 * p.nbins + 2) * sizeof(double) + (COUNT ? (size_t)p.nbins * sizeof(unsigned) : 0);
   if (lds > ctx->lds_per_cu) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "x pass needs %zu B LDS", lds);
   const bool seg = p.seglen != NC;
-  auto kern = seg ? fft_x_pass<NC, T, MODE, true, COUNT> : fft_x_pass<NC, T, MODE, false, COUNT>;
+  auto kern = seg ? fft_x_pass<NC, T, MODE, true, COUNT, false> : fft_x_pass<NC, T, MODE, false, COUNT, false>;
+  if constexpr (MODE == 0 && NC >= 32) {
+    if (fast) kern = seg ? fft_x_pass<NC, T, MODE, true, COUNT, true> : fft_x_pass<NC, T, MODE, false, COUNT, true>;
+  }
   if (lds > 64 * 1024)
     VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -762,9 +828,9 @@ int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const
     p.psum = psum_dev;
     p.nsample = nsample_dev;
     if (mode == 0) {
-      VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 0, true>(ctx, p)));
+      VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 0, true>(ctx, p, ctx->bin_fast)));
     } else {
-      VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 0, false>(ctx, p)));
+      VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 0, false>(ctx, p, ctx->bin_fast)));
     }
   } else if (mode == 1) {
     if (!out_dev) return vps_fail(ctx, VPS_ERR_ARG, "null output");
@@ -772,8 +838,10 @@ int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const
   } else if (mode == 2) {
     if (!out_dev) return vps_fail(ctx, VPS_ERR_ARG, "null output");
     VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 2>(ctx, p)));
+  } else if (mode == 4) {
+    VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 4>(ctx, p)));
   } else {
-    return vps_fail(ctx, VPS_ERR_ARG, "mode must be 0, 1, 2 or 3");
+    return vps_fail(ctx, VPS_ERR_ARG, "mode must be 0..4");
   }
   return rc;
 }

@@ -35,6 +35,7 @@ struct vps_ctx {
   double* d_k2 = nullptr;   // [N]
   double* d_thr = nullptr;  // [nbins+1]
   double edge0 = 0.0, inv_spacing = 0.0;
+  bool bin_fast = false;    // k2 table symmetric and monotone: mirrored-kx binning is valid
   std::vector<double> h_k2, h_thr;  // host copies, to skip re-uploading identical tables
 
   // small device scratch for the NN lattice axes

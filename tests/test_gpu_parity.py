@@ -204,6 +204,33 @@ def test_fused_binning_matches_oracle(K, N, L, flavour):
     assert np.allclose(tab[ok, 1], ref[ok, 1], rtol=PSUM_RTOL, atol=0)
 
 
+@pytest.mark.parametrize("N,L", [(32, 1.0), (64, 2.5), (256, 1.0)])
+def test_general_binning_path_matches_fast_path(K, N, L, monkeypatch):
+    """The branch-free mirrored-kx path and the general shell walk give the same counts
+    (bit for bit) and sums; custom narrow bins exercise several shells per kx step."""
+    from vpower import device
+    rng = np.random.default_rng(N + 1)
+    fields = [K.to_device(rng.standard_normal((N, N, N)).astype(np.float32)) for _ in range(2)]
+    out = {}
+    for kres in (None, 0.37 * 2 * np.pi / L):
+        for general in (False, True):
+            if general:
+                monkeypatch.setenv("VPS_NO_FAST_BINNING", "1")
+            else:
+                monkeypatch.delenv("VPS_NO_FAST_BINNING", raising=False)
+            pipe = device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False), kres=kres)
+            out[general] = pipe.finish(*pipe.accumulate(fields))
+        assert np.array_equal(out[False][:, 3], out[True][:, 3])
+        assert np.allclose(out[False][:, 2], out[True][:, 2], rtol=1e-6, atol=0)
+        ref = orc.spectrum_table(orc.vector_power(fields[0].cpu().numpy().astype(np.float64),
+                                                  fields[1].cpu().numpy().astype(np.float64),
+                                                  np.zeros((N, N, N)), L, N), L, N, "library", kres=kres)
+        ref[:, 1] /= np.where(ref[:, 0] > 0, 4 * np.pi * ref[:, 0] ** 2, 1)
+        assert np.array_equal(out[False][:, 3], ref[:, 3])
+        assert np.allclose(out[False][:, 2], ref[:, 2], rtol=PSUM_RTOL, atol=0)
+    monkeypatch.delenv("VPS_NO_FAST_BINNING", raising=False)
+
+
 @pytest.mark.parametrize("N", [16, 32, 64, 128])
 def test_nsample_golden(K, N):
     from vpower import device
