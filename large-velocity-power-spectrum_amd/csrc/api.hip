@@ -1,5 +1,6 @@
 // Context, memory, timing and binning-table entry points of the C ABI.
 #include <cstdarg>
+#include <cmath>
 #include <cstdlib>
 
 #include "vps_internal.h"
@@ -82,6 +83,7 @@ int vps_destroy(vps_ctx* ctx) {
   if (ctx->d_k2) (void)hipFree(ctx->d_k2);
   if (ctx->d_thr) (void)hipFree(ctx->d_thr);
   if (ctx->d_axes) (void)hipFree(ctx->d_axes);
+  if (ctx->d_xpart) (void)hipFree(ctx->d_xpart);
   for (auto& l : ctx->launches) {
     (void)hipEventDestroy(l.start);
     (void)hipEventDestroy(l.stop);
@@ -215,6 +217,10 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
   bool fast = (N % 2 == 0) && !getenv("VPS_NO_FAST_BINNING");
   for (int i = 1; fast && i < N / 2; ++i) fast = (k2_axis_host[N - i] == k2_axis_host[i]);
   for (int i = 0; fast && i < N / 2; ++i) fast = (k2_axis_host[i] <= k2_axis_host[i + 1]);
+  // ... and uniform edges, so that the float guess (sqrt(s)-edge0)*inv_spacing is within one
+  // shell of the truth (both reference flavours, np.arange and np.linspace, are uniform)
+  for (int i = 0; fast && i <= nbins; ++i)
+    fast = fabs((sqrt(thr_host[i]) - edge0) * inv_spacing - (double)i) < 1e-3;
   // unchanged tables (the usual case inside a loop over fields/steps): nothing to do
   if (ctx->d_k2 && ctx->bin_fast == fast && ctx->bin_N == N && ctx->nbins == nbins && ctx->edge0 == edge0 &&
       ctx->inv_spacing == inv_spacing && (int)ctx->h_k2.size() == N &&

@@ -20,6 +20,8 @@
 // each; radix-8/16 butterflies run in registers and the stages exchange data through
 // a padded per-line LDS buffer (Stockham autosort: stage inputs are always read at
 // stride NC/R, outputs written at expand(j)+r*Ns).
+#include <cstdlib>
+
 #include "vps_internal.h"
 
 namespace {
@@ -365,6 +367,9 @@ struct XParams {
   float edge0, inv_spacing;
   double* psum;
   unsigned long long* nsample;
+  int pair;  // FAST path: tiles pair ky with N-ky (needs whole ky ranges: line0, nlines multiples of N)
+  double* part_sum;    // [grid][nbins] per-workgroup partial shell sums
+  unsigned* part_cnt;  // [grid][nbins] per-workgroup partial shell counts
 };
 
 // FAST (MODE 0 only): the k^2 table is symmetric (k2[N-i] == k2[i]) and non-decreasing on
@@ -410,32 +415,76 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   cf* line = buf + t * PI::PITCH;
   const int segmask = p.seglen - 1;
   const long long ntiles = (p.nlines + T - 1) / T;
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long li = tile * T + t;  // local line index
-    const bool live = li < p.nlines;
-    cf v[RL];
-    {
-      constexpr int R = PI::R0, NB = RL / R;
-      const cf* base = p.in + li * p.seglen;
-#pragma unroll
-      for (int m = 0; m < NB; ++m)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int x = l + L * m + r * (NC / R);
-          if constexpr (SEG) {
-            // element x of the line sits in segment x >> seg_shift at offset x & segmask
-            v[m * R + r] = live ? base[(long long)(x >> p.seg_shift) * p.seg_stride + (x & segmask)]
-                                : make_float2(0.f, 0.f);
-          } else {
-            v[m * R + r] = live ? base[x] : make_float2(0.f, 0.f);
-          }
-        }
+  // PAIR (FAST path on whole ky ranges): a tile holds T/2 lines ky and their mirrors N-ky,
+  // which share every s with them, so one lane bins four modes (+-kx, +-ky) per step.
+  constexpr bool CANPAIR = FAST && (T >= 2) && (NC >= T) && (NC % T == 0);
+  const bool pair = CANPAIR && p.pair;
+  constexpr int TH = (T >= 2) ? T / 2 : 1;
+  // tile -> this lane's line, and the loads of its stage-0 inputs
+  long long li = 0;
+  bool live = false, mirrored = false, has_partner = false;
+  double k2y = 0.0, k2z = 0.0;   // fl(ky*ky), fl(kz*kz) of the line (MODE 0)
+  unsigned wz = 1u;              // Hermitian multiplicity of its kz plane
+  double k2half = 0.0;
+  if constexpr (MODE == 0) k2half = p.k2[NC / 2];
+  cf v[RL];
+  auto locate_line = [&](long long tile) {
+    li = tile * T + t;       // local line index
+    mirrored = false;        // this line is the N-ky partner of line t - TH
+    has_partner = false;     // line t + TH holds this line's N-ky partner
+    if (pair) {
+      constexpr long long tiles_per_plane = (NC / T) > 0 ? (NC / T) : 1;
+      const long long plane = tile / tiles_per_plane;
+      const int q = (int)(tile % tiles_per_plane);
+      const int ky_a = q * TH + (t % TH);
+      const int ky = (t < TH) ? ky_a : (ky_a == 0 ? NC / 2 : NC - ky_a);
+      li = plane * NC + ky;
+      mirrored = (t >= TH) && (ky_a != 0);
+      has_partner = (t < TH) && (ky_a != 0);
     }
+    live = li < p.nlines;
+    if constexpr (MODE == 0) {
+      if (live) {
+        const long long g = p.line0 + li;
+        const int kz = p.kz0 + (int)(g / p.N);
+        k2y = p.k2[(int)(g % p.N)];
+        k2z = p.k2[kz];
+        wz = (kz == 0 || 2 * kz == p.N) ? 1u : 2u;
+      }
+    }
+  };
+  auto load_line = [&]() {
+    constexpr int R = PI::R0, NB = RL / R;
+    const cf* base = p.in + li * p.seglen;
+#pragma unroll
+    for (int m = 0; m < NB; ++m)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int x = l + L * m + r * (NC / R);
+        if constexpr (SEG) {
+          // element x of the line sits in segment x >> seg_shift at offset x & segmask
+          v[m * R + r] = live ? base[(long long)(x >> p.seg_shift) * p.seg_stride + (x & segmask)]
+                              : make_float2(0.f, 0.f);
+        } else {
+          v[m * R + r] = live ? base[x] : make_float2(0.f, 0.f);
+        }
+      }
+  };
+  if ((long long)blockIdx.x < ntiles) {
+    locate_line(blockIdx.x);
+    load_line();
+  }
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // line bookkeeping of THIS tile (v already holds, or is receiving, its inputs)
+    const long long li_cur = li;
+    const bool live_cur = live, mirrored_cur = mirrored, partner_cur = has_partner;
+    const double k2y_cur = k2y, k2z_cur = k2z;
+    const unsigned wz_cur = wz;
     __syncthreads();  // previous tile's readers are done with the line buffers
     fft_from_regs<NC>(v, line, tw, l);
     if constexpr (MODE == 1) {
-      if (live) {
-        cf* o = p.out + li * (long long)NC;
+      if (live_cur) {
+        cf* o = p.out + li_cur * (long long)NC;
 #pragma unroll
         for (int i = 0; i < RL; ++i) o[out_index<NC>(l, i)] = v[i];
       }
@@ -444,8 +493,8 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
 #pragma unroll
       for (int i = 0; i < RL; ++i) asm volatile("" ::"v"(v[i].x), "v"(v[i].y));
     } else if constexpr (MODE == 2) {
-      if (live) {
-        float* o = reinterpret_cast<float*>(p.out) + li * (long long)NC;
+      if (live_cur) {
+        float* o = reinterpret_cast<float*>(p.out) + li_cur * (long long)NC;
 #pragma unroll
         for (int i = 0; i < RL; ++i) o[out_index<NC>(l, i)] += v[i].x * v[i].x + v[i].y * v[i].y;
       }
@@ -463,60 +512,65 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
         pw[k + k / CH] = v[i].x * v[i].x + v[i].y * v[i].y;
       }
       __syncthreads();
+      // v is dead from here on: start fetching the next tile's lines so that the loads are
+      // in flight while this tile is binned
+      if (tile + gridDim.x < ntiles) {
+        locate_line(tile + gridDim.x);
+        load_line();
+      }
       if constexpr (FAST) {
-        if (live) {
-          const long long g = p.line0 + li;
-          const int ky = (int)(g % p.N);
-          const int kz = p.kz0 + (int)(g / p.N);
-          const double k2y = p.k2[ky], k2z = p.k2[kz];
-          const unsigned w = (kz == 0 || 2 * kz == p.N) ? 1u : 2u;
-          const double wd = (double)w;
+        if (live_cur && !mirrored_cur) {
+          const unsigned w = wz_cur * (partner_cur ? 2u : 1u);
+          const float wf = (float)wz_cur;
+          // the partner line's |F|^2 image sits TH line buffers further on
+          constexpr int POFF = TH * PI::PITCH * 2;
           const float* mine = pw + l * (H + 1);                        // kx = l*H + i
           const float* mirr = pw + (NC + NC / H - 1) - l * (H + 1);    // NC-kx for i >= 1 at mirr[-i]
-          double s = (k2x[0] + k2y) + k2z;
-          int cur = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
-          cur = min(max(cur, 0), p.nbins - 1);
-          while (cur > 0 && s < thr[cur]) --cur;
-          while (cur < p.nbins - 1 && s >= thr[cur + 1]) ++cur;
-          if (s < thr[cur]) cur = -1;
-          else if (s >= thr[cur + 1]) cur = p.nbins;
-          double nxt = thr[cur + 1];
-#pragma unroll
-          for (int i = 0; i < H; ++i) {
+          // Every |kx| is binned independently (no chain between the LDS reads): the edges
+          // are uniform (checked by vps_set_binning), so the float guess is off by at most
+          // one shell and is corrected against the exact float64 thresholds.
+          auto bin_one = [&](int i, double k2xi) {
+            // s = (kx*kx + ky*ky) + kz*kz with numpy's rounding (the table holds fl(k*k))
+            const double s = (k2xi + k2y_cur) + k2z_cur;
+            int g = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
+            g = min(max(g, 0), p.nbins - 1);
+            const double lo = thr[g], hi = thr[g + 1];
+            const int bin = g - ((s < lo) ? 1 : 0) + ((s >= hi) ? 1 : 0);
             float pv = mine[i];
+            if (partner_cur) pv += mine[i + POFF];
             unsigned c = 1u;
             if (i > 0) {
-              // s = (kx*kx + ky*ky) + kz*kz with numpy's rounding (the table holds fl(k*k))
-              s = (k2x[i] + k2y) + k2z;
-              cur += (s >= nxt) ? 1 : 0;
-              nxt = thr[cur + 1];
-              while (s >= nxt) nxt = thr[++cur + 1];   // bins narrower than one kx step only
               pv += mirr[-i];
+              if (partner_cur) pv += mirr[POFF - i];
               c = 2u;
             } else if (l > 0) {
               pv += mirr[1];
+              if (partner_cur) pv += mirr[POFF + 1];
               c = 2u;
             }
-            if ((unsigned)cur < (unsigned)p.nbins) {
-              atomicAdd(&hsum[cur], (double)pv * wd);
-              if constexpr (COUNT) atomicAdd(&hcnt[cur], c * w);
+            if ((unsigned)bin < (unsigned)p.nbins) {
+              atomicAdd(&hsum[bin], (double)(pv * wf));
+              if constexpr (COUNT) atomicAdd(&hcnt[bin], c * w);
             }
-          }
+          };
+#pragma unroll
+          for (int i = 0; i < H; ++i) bin_one(i, k2x[i]);
           if (l == L - 1) {   // the unpaired kx = NC/2 mode
-            s = (p.k2[NC / 2] + k2y) + k2z;
-            while (s >= nxt) nxt = thr[++cur + 1];
-            if ((unsigned)cur < (unsigned)p.nbins) {
-              atomicAdd(&hsum[cur], (double)pw[NC / 2 + L] * wd);
-              if constexpr (COUNT) atomicAdd(&hcnt[cur], w);
+            const double s = (k2half + k2y_cur) + k2z_cur;
+            int g = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
+            g = min(max(g, 0), p.nbins - 1);
+            const int bin = g - ((s < thr[g]) ? 1 : 0) + ((s >= thr[g + 1]) ? 1 : 0);
+            if ((unsigned)bin < (unsigned)p.nbins) {
+              float pv = pw[NC / 2 + L];
+              if (partner_cur) pv += pw[NC / 2 + L + POFF];
+              atomicAdd(&hsum[bin], (double)(pv * wf));
+              if constexpr (COUNT) atomicAdd(&hcnt[bin], w);
             }
           }
         }
-      } else if (live) {
-        const long long g = p.line0 + li;
-        const int ky = (int)(g % p.N);
-        const int kz = p.kz0 + (int)(g / p.N);
-        const double k2y = p.k2[ky], k2z = p.k2[kz];
-        const unsigned w = (kz == 0 || 2 * kz == p.N) ? 1u : 2u;
+      } else if (live_cur) {
+        const double k2y = k2y_cur, k2z = k2z_cur;
+        const unsigned w = wz_cur;
         const double wd = (double)w;
         // walk the chunk in the direction of non-decreasing |kx| (k2x was loaded that way)
         const float* mine = pw + l * (RL + 1) + (rev ? RL - 1 : 0);
@@ -563,18 +617,44 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
         flush();
       }
     }
-  }
-  if constexpr (MODE == 0) {
-    __syncthreads();
-    for (int i = tid; i < p.nbins; i += NT) {
-      const double hs = hsum[i];
-      if (hs != 0.0) atomicAdd(&p.psum[i], hs);
-      if constexpr (COUNT) {
-        const unsigned c = hcnt[i];
-        if (c) atomicAdd(&p.nsample[i], (unsigned long long)c);
+    if constexpr (MODE != 0) {
+      if (tile + gridDim.x < ntiles) {
+        locate_line(tile + gridDim.x);
+        load_line();
       }
     }
   }
+  if constexpr (MODE == 0) {
+    // Per-workgroup partial shell sums go out with plain stores; reduce_partials adds them
+    // up.  (Hundreds of workgroups doing float64 atomics on the same few cache lines of
+    // psum serialise at the memory side and cost as much as the whole transform.)
+    __syncthreads();
+    double* ps = p.part_sum + (size_t)blockIdx.x * p.nbins;
+    unsigned* pc = p.part_cnt + (size_t)blockIdx.x * p.nbins;
+    for (int i = tid; i < p.nbins; i += NT) {
+      ps[i] = hsum[i];
+      if constexpr (COUNT) pc[i] = hcnt[i];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    reduce_partials(const double* __restrict__ part_sum, const unsigned* __restrict__ part_cnt, int nparts,
+                    int nbins, double* __restrict__ psum, unsigned long long* __restrict__ nsample) {
+  // grid = (bins / 256, groups): block (., g) sums a slice of the partials for 256 bins
+  // and adds it with one atomic per bin (only gridDim.y adders per address)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nbins) return;
+  const int per = (nparts + gridDim.y - 1) / gridDim.y;
+  const int w0 = blockIdx.y * per, w1 = min(w0 + per, nparts);
+  double s = 0.0;
+  unsigned long long c = 0;
+  for (int w = w0; w < w1; ++w) {
+    s += part_sum[(size_t)w * nbins + i];
+    if (part_cnt) c += part_cnt[(size_t)w * nbins + i];
+  }
+  if (s != 0.0) atomicAdd(&psum[i], s);
+  if (part_cnt && c) atomicAdd(&nsample[i], c);
 }
 
 template <int NC>
@@ -621,7 +701,8 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
 }
 
 template <int NC, int MODE, bool COUNT = false>
-int launch_x(vps_ctx* ctx, const XParams& p, bool fast = false) {
+int launch_x(vps_ctx* ctx, const XParams& p_in, bool fast = false) {
+  XParams p = p_in;
   constexpr int T = xpass_T<NC>();
   typedef PlanInfo<NC> PI;
   size_t lds = (((PI::TW + 1) & ~1) + (size_t)T * PI::PITCH) * sizeof(cf);
@@ -635,16 +716,35 @@ int launch_x(vps_ctx* ctx, const XParams& p, bool fast = false) {
   if (lds > 64 * 1024)
     VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (const char* e = getenv("VPS_EXP_XLDS_PAD")) lds += (size_t)atol(e);   // experiments only
   const long long ntiles = (p.nlines + T - 1) / T;
   long long per_cu = (long long)(ctx->lds_per_cu / (lds ? lds : 1));
+  if (const char* e = getenv("VPS_EXP_XPERCU")) per_cu = atol(e);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
   long long grid = (long long)ctx->num_cu * per_cu;
   if (grid > ntiles) grid = ntiles;
   if (grid < 1) return VPS_OK;
+  if (MODE == 0) {
+    const size_t need = (size_t)grid * p.nbins * (sizeof(double) + sizeof(unsigned));
+    if (need > ctx->xpart_cap) {
+      VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_xpart) VPS_HIP_CHECK(ctx, hipFree(ctx->d_xpart));
+      ctx->d_xpart = nullptr;
+      ctx->xpart_cap = 0;
+      VPS_HIP_CHECK(ctx, hipMalloc(&ctx->d_xpart, need));
+      ctx->xpart_cap = need;
+    }
+    p.part_sum = reinterpret_cast<double*>(ctx->d_xpart);
+    p.part_cnt = reinterpret_cast<unsigned*>(p.part_sum + (size_t)grid * p.nbins);
+  }
   {
     vps_launch_timer tm(ctx, VPS_K_FFT_X);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(T * PI::L), lds, ctx->stream, p);
+    if (MODE == 0)
+      hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((p.nbins + 255) / 256), grid >= 64 ? 32u : 1u),
+                         dim3(256), 0, ctx->stream,
+                         p.part_sum, COUNT ? p.part_cnt : nullptr, (int)grid, p.nbins, p.psum, p.nsample);
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
   return VPS_OK;
@@ -827,6 +927,7 @@ int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const
     p.inv_spacing = (float)ctx->inv_spacing;
     p.psum = psum_dev;
     p.nsample = nsample_dev;
+    p.pair = (ctx->bin_fast && line0 % N == 0 && nlines % N == 0 && !getenv("VPS_NO_PAIR_BINNING")) ? 1 : 0;
     if (mode == 0) {
       VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 0, true>(ctx, p, ctx->bin_fast)));
     } else {

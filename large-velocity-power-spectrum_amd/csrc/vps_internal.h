@@ -38,6 +38,10 @@ struct vps_ctx {
   bool bin_fast = false;    // k2 table symmetric and monotone: mirrored-kx binning is valid
   std::vector<double> h_k2, h_thr;  // host copies, to skip re-uploading identical tables
 
+  // per-workgroup partial shell sums of the x pass
+  void* d_xpart = nullptr;
+  size_t xpart_cap = 0;
+
   // small device scratch for the NN lattice axes
   double* d_axes = nullptr;
   size_t axes_cap = 0;

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, "csrc")
-LIB_PATH = os.path.join(_HERE, "libvps_hip.so")
+LIB_PATH = os.environ.get("VPS_LIB_PATH") or os.path.join(_HERE, "libvps_hip.so")  # override: experiments only
 SOURCES = ("api.hip", "deposit.hip", "nn.hip", "fft.hip", "hist.hip")
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics")
 

@@ -213,15 +213,18 @@ def test_general_binning_path_matches_fast_path(K, N, L, monkeypatch):
     fields = [K.to_device(rng.standard_normal((N, N, N)).astype(np.float32)) for _ in range(2)]
     out = {}
     for kres in (None, 0.37 * 2 * np.pi / L):
-        for general in (False, True):
-            if general:
+        for general in (False, True, "nopair"):
+            monkeypatch.delenv("VPS_NO_FAST_BINNING", raising=False)
+            monkeypatch.delenv("VPS_NO_PAIR_BINNING", raising=False)
+            if general is True:
                 monkeypatch.setenv("VPS_NO_FAST_BINNING", "1")
-            else:
-                monkeypatch.delenv("VPS_NO_FAST_BINNING", raising=False)
+            elif general == "nopair":
+                monkeypatch.setenv("VPS_NO_PAIR_BINNING", "1")
             pipe = device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False), kres=kres)
             out[general] = pipe.finish(*pipe.accumulate(fields))
-        assert np.array_equal(out[False][:, 3], out[True][:, 3])
-        assert np.allclose(out[False][:, 2], out[True][:, 2], rtol=1e-6, atol=0)
+        for other in (True, "nopair"):
+            assert np.array_equal(out[False][:, 3], out[other][:, 3])
+            assert np.allclose(out[False][:, 2], out[other][:, 2], rtol=1e-6, atol=0)
         ref = orc.spectrum_table(orc.vector_power(fields[0].cpu().numpy().astype(np.float64),
                                                   fields[1].cpu().numpy().astype(np.float64),
                                                   np.zeros((N, N, N)), L, N), L, N, "library", kres=kres)
@@ -229,6 +232,7 @@ def test_general_binning_path_matches_fast_path(K, N, L, monkeypatch):
         assert np.array_equal(out[False][:, 3], ref[:, 3])
         assert np.allclose(out[False][:, 2], ref[:, 2], rtol=PSUM_RTOL, atol=0)
     monkeypatch.delenv("VPS_NO_FAST_BINNING", raising=False)
+    monkeypatch.delenv("VPS_NO_PAIR_BINNING", raising=False)
 
 
 @pytest.mark.parametrize("N", [16, 32, 64, 128])
