@@ -154,6 +154,10 @@ struct PlanInfo {
   static constexpr int TW1 = (R1 > 1) ? (R1 - 1) * NS1 : 0;
   static constexpr int TW2 = (R2 > 1) ? (R2 - 1) * NS2 : 0;
   static constexpr int TW = TW1 + TW2;  // entries of the per-stage twiddle image
+  // the image is staged in LDS except for the longest lines, where the tile itself needs
+  // nearly all of the 160 KiB (the table then stays in L2)
+  static constexpr bool TWLDS = NC <= 2048;
+  static constexpr int TWL = TWLDS ? ((TW + 1) & ~1) : 0;  // LDS entries reserved for it
   // LDS line pitch (complex elements): one pad slot per 32 elements
   static constexpr int PITCH = NC + (NC >> 5) + 1;
   static_assert(R0 * R1 * R2 == NC, "bad plan");
@@ -270,8 +274,9 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
   typedef PlanInfo<NC> PI;
   constexpr int L = PI::L, RL = PI::RL, NT = T * L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  cf* tw = reinterpret_cast<cf*>(smem_raw);
-  cf* buf = tw + ((PI::TW + 1) & ~1);
+  cf* tw_lds = reinterpret_cast<cf*>(smem_raw);
+  cf* buf = tw_lds + PI::TWL;
+  const cf* tw = PI::TWLDS ? tw_lds : p.tw_stage;
 
   const int tid = threadIdx.x;
   const int t = tid / L, l = tid % L;
@@ -279,7 +284,8 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
   const int b = blockIdx.x / tiles;
   const int a0 = (blockIdx.x % tiles) * T;
 
-  for (int i = tid; i < PI::TW; i += NT) tw[i] = p.tw_stage[i];
+  if constexpr (PI::TWLDS)
+    for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
 
   cf v[RL];
   {
@@ -385,13 +391,15 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   // carve: thr (double, nbins+2 with a +inf sentinel) | hsum (double) | tw | line buffers | hcnt
   double* thr = reinterpret_cast<double*>(smem_raw);
   double* hsum = thr + (MODE == 0 ? (p.nbins + 2) : 0);
-  cf* tw = reinterpret_cast<cf*>(hsum + (MODE == 0 ? p.nbins : 0));
-  cf* buf = tw + ((PI::TW + 1) & ~1);
+  cf* tw_lds = reinterpret_cast<cf*>(hsum + (MODE == 0 ? p.nbins : 0));
+  cf* buf = tw_lds + PI::TWL;
+  const cf* tw = PI::TWLDS ? tw_lds : p.tw_stage;
   unsigned* hcnt = reinterpret_cast<unsigned*>(buf + T * PI::PITCH);
 
   const int tid = threadIdx.x;
   const int t = tid / L, l = tid % L;
-  for (int i = tid; i < PI::TW; i += NT) tw[i] = p.tw_stage[i];
+  if constexpr (PI::TWLDS)
+    for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
   // fl(kx*kx) of this lane's contiguous chunk of RL kx values, ordered by non-decreasing
   // |kx|: the chunks of the negative-frequency half (index >= NC/2) are walked backwards
   double k2x[MODE == 0 ? (FAST ? H : RL) : 1];
@@ -677,7 +685,7 @@ size_t transpose_lds_bytes() {
   typedef PlanInfo<NC> PI;
   size_t lines = (size_t)T * PI::PITCH;
   size_t tr = (size_t)NC * T;
-  return (((PI::TW + 1) & ~1) + (lines > tr ? lines : tr)) * sizeof(cf);
+  return (PI::TWL + (lines > tr ? lines : tr)) * sizeof(cf);
 }
 
 template <int NC, bool REAL>
@@ -705,7 +713,7 @@ int launch_x(vps_ctx* ctx, const XParams& p_in, bool fast = false) {
   XParams p = p_in;
   constexpr int T = xpass_T<NC>();
   typedef PlanInfo<NC> PI;
-  size_t lds = (((PI::TW + 1) & ~1) + (size_t)T * PI::PITCH) * sizeof(cf);
+  size_t lds = (PI::TWL + (size_t)T * PI::PITCH) * sizeof(cf);
   if (MODE == 0) lds += (size_t)(2 * p.nbins + 2) * sizeof(double) + (COUNT ? (size_t)p.nbins * sizeof(unsigned) : 0);
   if (lds > ctx->lds_per_cu) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "x pass needs %zu B LDS", lds);
   const bool seg = p.seglen != NC;
