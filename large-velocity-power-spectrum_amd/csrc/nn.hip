@@ -97,10 +97,12 @@ __global__ void __launch_bounds__(256)
   atomicAdd(&count[((long long)cx * g.M + cy) * g.M + cz], 1u);
 }
 
+// sorted record of a particle: float32 position (exact for float32 input, rounded for
+// float64 input) + original index, one 16-byte load per candidate
 template <typename F>
 __global__ void __launch_bounds__(256)
     nn_fill_kernel(const F* __restrict__ pos, long long np, NnGrid g, const unsigned* __restrict__ start,
-                   unsigned* __restrict__ fill, F* __restrict__ spos, int* __restrict__ sidx) {
+                   unsigned* __restrict__ fill, float4* __restrict__ srec) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= np) return;
   const F px = pos[i * 3 + 0], py = pos[i * 3 + 1], pz = pos[i * 3 + 2];
@@ -109,34 +111,180 @@ __global__ void __launch_bounds__(256)
   const int cz = cell_coord((double)pz, g.lo[2], g.inv_w[2], g.M);
   const long long c = ((long long)cx * g.M + cy) * g.M + cz;
   const unsigned slot = start[c] + atomicAdd(&fill[c], 1u);
-  spos[(long long)slot * 3 + 0] = px;
-  spos[(long long)slot * 3 + 1] = py;
-  spos[(long long)slot * 3 + 2] = pz;
-  sidx[slot] = (int)i;
+  srec[slot] = make_float4((float)px, (float)py, (float)pz, __int_as_float((int)i));
+}
+
+// One thread per lattice point; a workgroup owns a tile of 1 x NN_TY x 64 lattice points
+// (z fastest, so results are stored 256 bytes at a time).  The cell columns that rings 0 and
+// 1 of every point of the tile can touch are staged in LDS once (bucket offsets + records),
+// so the per-lane ring search reads LDS instead of issuing scattered global loads; points
+// that need ring 2 or more (rare at about one particle per cell) continue from global memory.
+// Candidates are screened in float32 against a bound that provably keeps every particle
+// whose exact float64 distance could tie or beat the best (err bounds the float32 distance
+// error); survivors are re-evaluated exactly in float64 from the original coordinates, with
+// the lowest-index tie rule.
+constexpr int NN_TY = 4;
+constexpr int NN_MAXCELL = 1024;   // staged bucket-offset entries (4 KiB)
+constexpr int NN_MAXREC = 1024;    // staged records (16 KiB)
+
+struct NnBest {
+  double best;
+  float screen;
+  int idx;
+};
+
+template <typename F>
+__device__ __forceinline__ void nn_consider(const F* __restrict__ pos, const float4 rec, const double (&Q)[3],
+                                            const float (&Qf)[3], float err, NnBest& b) {
+  const float fx = Qf[0] - rec.x, fy = Qf[1] - rec.y, fz = Qf[2] - rec.z;
+  const float d2f = (fx * fx + fy * fy) + fz * fz;
+  if (d2f > b.screen) return;
+  const int oi = __float_as_int(rec.w);
+  double px, py, pz;
+  if constexpr (sizeof(F) == 4) {
+    px = (double)rec.x; py = (double)rec.y; pz = (double)rec.z;   // exact
+  } else {
+    px = pos[(long long)oi * 3 + 0]; py = pos[(long long)oi * 3 + 1]; pz = pos[(long long)oi * 3 + 2];
+  }
+  const double dx = Q[0] - px, dy = Q[1] - py, dz = Q[2] - pz;
+  double d2 = dx * dx;
+  d2 = d2 + dy * dy;
+  d2 = d2 + dz * dz;
+  if (d2 < b.best || (d2 == b.best && oi < b.idx)) {
+    b.best = d2;
+    b.idx = oi;
+    // anything with true distance <= sqrt(best) has float32 distance <= sqrt(best)+err
+    const float rb = (float)sqrt(d2) * 1.000001f + err;
+    b.screen = rb * rb * 1.000001f;
+  }
+}
+
+// true when everything outside the searched (2r+1)^3 block is provably farther than best
+__device__ __forceinline__ bool nn_done(const NnGrid& g, const int (&c)[3], const double (&Q)[3], int r,
+                                        double best, bool& exhausted) {
+  const int M = g.M;
+  double bound = INFINITY;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (c[a] + r + 1 <= M - 1) bound = fmin(bound, (g.lo[a] + (double)(c[a] + r + 1) * g.w[a]) - Q[a]);
+    if (c[a] - r - 1 >= 0) bound = fmin(bound, Q[a] - (g.lo[a] + (double)(c[a] - r) * g.w[a]));
+  }
+  exhausted = (bound == INFINITY);  // whole grid searched
+  if (exhausted) return true;
+  // slack: a particle may sit one rounding error outside its cell's nominal extent
+  bound -= 1e-6 * fmax(g.w[0], fmax(g.w[1], g.w[2]));
+  return bound > 0.0 && best < bound * bound;
 }
 
 template <typename F, int C>
-__global__ void __launch_bounds__(256)
-    nn_query_kernel(const F* __restrict__ spos, const int* __restrict__ sidx,
-                    const unsigned* __restrict__ start, NnGrid g, const double* __restrict__ qx,
-                    const double* __restrict__ qy, const double* __restrict__ qz, int x0, int nx,
-                    int nqy, int nqz, const float* __restrict__ payload, float* __restrict__ out,
+__global__ void __launch_bounds__(64 * NN_TY)
+    nn_query_kernel(const F* __restrict__ pos, const float4* __restrict__ srec,
+                    const unsigned* __restrict__ start, NnGrid g, float err,
+                    const double* __restrict__ qx, const double* __restrict__ qy,
+                    const double* __restrict__ qz, int x0, int nx, int nqy, int nqz,
+                    const float* __restrict__ payload, float* __restrict__ out,
                     int* __restrict__ nn_idx) {
-  const long long nq = (long long)nx * nqy * nqz;
-  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nq) return;
-  const int iz = (int)(q % nqz);
-  const int iy = (int)((q / nqz) % nqy);
-  const int ix = (int)(q / ((long long)nqz * nqy));
-  const double Q[3] = {qx[x0 + ix], qy[iy], qz[iz]};
+  __shared__ unsigned lstart[NN_MAXCELL];
+  __shared__ float4 lrec[NN_MAXREC];
+  __shared__ int range[4];        // min cy, max cy, min cz, max cz over the tile
+  __shared__ unsigned colbase[65];
+  __shared__ int staged_flag;
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tz = (nqz + 63) / 64, ty = (nqy + NN_TY - 1) / NN_TY;
+  const long long tile = blockIdx.x;
+  const int iz = (int)(tile % tz) * 64 + lane;
+  const int iy = (int)((tile / tz) % ty) * NN_TY + wv;
+  const int ix = (int)(tile / ((long long)tz * ty));
+  const bool valid = iz < nqz && iy < nqy;
   const int M = g.M;
+  double Q[3] = {qx[x0 + ix], valid ? qy[iy] : qy[0], valid ? qz[iz] : qz[0]};
+  const float Qf[3] = {(float)Q[0], (float)Q[1], (float)Q[2]};
   int c[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) c[a] = cell_coord(Q[a], g.lo[a], g.inv_w[a], M);
 
-  double best = INFINITY;
-  int best_i = 0x7fffffff;
-  for (int r = 0; r < M; ++r) {
+  if (threadIdx.x == 0) {
+    range[0] = M; range[1] = -1; range[2] = M; range[3] = -1;
+  }
+  __syncthreads();
+  if (valid) {
+    atomicMin(&range[0], c[1]);
+    atomicMax(&range[1], c[1]);
+    atomicMin(&range[2], c[2]);
+    atomicMax(&range[3], c[2]);
+  }
+  __syncthreads();
+  // cell columns that rings 0 and 1 of the whole tile can touch (all points share c[0])
+  const int cx0 = max(c[0] - 1, 0), cx1 = min(c[0] + 1, M - 1);
+  const int cy0 = max(range[0] - 1, 0), cy1 = min(range[1] + 1, M - 1);
+  const int cz0 = max(range[2] - 1, 0), cz1 = min(range[3] + 1, M - 1);
+  const int ncx = cx1 - cx0 + 1, ncy = cy1 - cy0 + 1, ncz = cz1 - cz0 + 1;
+  const int ncol = ncx * ncy;
+  const bool fits = range[1] >= 0 && ncol <= 64 && ncol * (ncz + 1) <= NN_MAXCELL;
+  if (fits && threadIdx.x < ncol) {
+    const long long row = ((long long)(cx0 + threadIdx.x / ncy) * M + (cy0 + threadIdx.x % ncy)) * M;
+    colbase[threadIdx.x + 1] = start[row + cz1 + 1] - start[row + cz0];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned tot = 0;
+    colbase[0] = 0;
+    if (fits)
+      for (int k = 1; k <= ncol; ++k) {
+        tot += colbase[k];
+        colbase[k] = tot;
+      }
+    staged_flag = (fits && tot <= NN_MAXREC) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool staged = staged_flag != 0;
+  if (staged) {
+    for (int col = wv; col < ncol; col += NN_TY) {
+      const long long row = ((long long)(cx0 + col / ncy) * M + (cy0 + col % ncy)) * M;
+      const unsigned g0 = start[row + cz0];
+      const unsigned base = colbase[col];
+      for (int k = lane; k <= ncz; k += 64) lstart[col * (ncz + 1) + k] = start[row + cz0 + k] - g0 + base;
+      const unsigned n = colbase[col + 1] - base;
+      for (unsigned j = lane; j < n; j += 64) lrec[base + j] = srec[g0 + j];
+    }
+  }
+  __syncthreads();
+
+  NnBest b{INFINITY, INFINITY, 0x7fffffff};
+  int r0 = 0;
+  bool finished = !valid;
+  if (staged && valid) {
+    for (int r = 0; r <= 1 && !finished; ++r) {
+      const int xlo = max(c[0] - r, 0), xhi = min(c[0] + r, M - 1);
+      const int ylo = max(c[1] - r, 0), yhi = min(c[1] + r, M - 1);
+      for (int cx = xlo; cx <= xhi; ++cx) {
+        const bool xedge = (cx == c[0] - r) || (cx == c[0] + r);
+        for (int cy = ylo; cy <= yhi; ++cy) {
+          const bool edge = xedge || (cy == c[1] - r) || (cy == c[1] + r);
+          const int colrow = ((cx - cx0) * ncy + (cy - cy0)) * (ncz + 1) - cz0;
+          const int nruns = (edge || r == 0) ? 1 : 2;
+          for (int run = 0; run < nruns; ++run) {
+            int z0, z1;
+            if (edge || r == 0) {
+              z0 = max(c[2] - r, 0);
+              z1 = min(c[2] + r, M - 1);
+            } else {
+              z0 = z1 = (run == 0) ? c[2] - r : c[2] + r;
+              if (z0 < 0 || z0 >= M) continue;
+            }
+            const unsigned s = lstart[colrow + z0], e = lstart[colrow + z1 + 1];
+            for (unsigned j = s; j < e; ++j) nn_consider<F>(pos, lrec[j], Q, Qf, err, b);
+          }
+        }
+      }
+      bool exhausted;
+      finished = nn_done(g, c, Q, r, b.best, exhausted);
+    }
+    r0 = 2;
+  }
+  // general search from global memory: rings r0, r0+1, ...
+  for (int r = r0; r < M && !finished; ++r) {
     const int xlo = max(c[0] - r, 0), xhi = min(c[0] + r, M - 1);
     const int ylo = max(c[1] - r, 0), yhi = min(c[1] + r, M - 1);
     for (int cx = xlo; cx <= xhi; ++cx) {
@@ -156,43 +304,25 @@ __global__ void __launch_bounds__(256)
             if (z0 < 0 || z0 >= M) continue;
           }
           const unsigned s = start[rowbase + z0], e = start[rowbase + z1 + 1];
-          for (unsigned j = s; j < e; ++j) {
-            const double dx = Q[0] - (double)spos[(long long)j * 3 + 0];
-            const double dy = Q[1] - (double)spos[(long long)j * 3 + 1];
-            const double dz = Q[2] - (double)spos[(long long)j * 3 + 2];
-            double d2 = dx * dx;
-            d2 = d2 + dy * dy;
-            d2 = d2 + dz * dz;
-            const int oi = sidx[j];
-            if (d2 < best || (d2 == best && oi < best_i)) {
-              best = d2;
-              best_i = oi;
-            }
-          }
+          for (unsigned j = s; j < e; ++j) nn_consider<F>(pos, srec[j], Q, Qf, err, b);
         }
       }
     }
-    // lower bound on the distance to anything outside the searched (2r+1)^3 block
-    double bound = INFINITY;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (c[a] + r + 1 <= M - 1) bound = fmin(bound, (g.lo[a] + (double)(c[a] + r + 1) * g.w[a]) - Q[a]);
-      if (c[a] - r - 1 >= 0) bound = fmin(bound, Q[a] - (g.lo[a] + (double)(c[a] - r) * g.w[a]));
-    }
-    if (bound == INFINITY) break;  // whole grid searched
-    // slack: a particle may sit one rounding error outside its cell's nominal extent
-    bound -= 1e-6 * fmax(g.w[0], fmax(g.w[1], g.w[2]));
-    if (bound > 0.0 && best < bound * bound) break;
+    bool exhausted;
+    finished = nn_done(g, c, Q, r, b.best, exhausted);
   }
-  if (nn_idx) nn_idx[q] = best_i;
+  if (!valid) return;
+  const long long nq = (long long)nx * nqy * nqz;
+  const long long q = ((long long)ix * nqy + iy) * nqz + iz;
+  if (nn_idx) nn_idx[q] = b.idx;
   if (out) {
 #pragma unroll
-    for (int ch = 0; ch < C; ++ch) out[(long long)ch * nq + q] = payload[(long long)best_i * C + ch];
+    for (int ch = 0; ch < C; ++ch) out[(long long)ch * nq + q] = payload[(long long)b.idx * C + ch];
   }
 }
 
 int nn_grid_side(int64_t np) {
-  double m = std::cbrt((double)np / 2.0);
+  double m = std::cbrt((double)np);   // about one particle per cell: ring 1 (27 cells) nearly always decides
   int M = (int)m;
   if (M < 1) M = 1;
   if (M > 1024) M = 1024;
@@ -200,7 +330,7 @@ int nn_grid_side(int64_t np) {
 }
 
 struct NnLayout {
-  size_t header, count, fill, start, tiles, spos, sidx, total;
+  size_t header, count, fill, start, tiles, srec, total;
   long long ncell, ntiles;
   int M;
 };
@@ -217,24 +347,22 @@ NnLayout nn_layout(int64_t np, int is_f64) {
   l.fill = off;   off = align(off + sizeof(unsigned) * l.ncell);
   l.start = off;  off = align(off + sizeof(unsigned) * (l.ncell + 1));
   l.tiles = off;  off = align(off + sizeof(unsigned) * (l.ntiles + 1));
-  l.spos = off;   off = align(off + (size_t)np * 3 * (is_f64 ? 8 : 4));
-  l.sidx = off;   off = align(off + (size_t)np * 4);
+  l.srec = off;   off = align(off + (size_t)np * sizeof(float4));
   l.total = off;
   return l;
 }
 
 template <typename F>
 int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, int x0, int nx,
-           int nqy, int nqz, const double* dqx, const double* dqy, const double* dqz, float* out,
-           int* nn_idx, char* work) {
+           int nqy, int nqz, const double* dqx, const double* dqy, const double* dqz, double qmax,
+           float* out, int* nn_idx, char* work) {
   const NnLayout l = nn_layout(np, sizeof(F) == 8);
   NnHeader* hdr = reinterpret_cast<NnHeader*>(work + l.header);
   unsigned* count = reinterpret_cast<unsigned*>(work + l.count);
   unsigned* fill = reinterpret_cast<unsigned*>(work + l.fill);
   unsigned* start = reinterpret_cast<unsigned*>(work + l.start);
   unsigned* tiles = reinterpret_cast<unsigned*>(work + l.tiles);
-  F* spos = reinterpret_cast<F*>(work + l.spos);
-  int* sidx = reinterpret_cast<int*>(work + l.sidx);
+  float4* srec = reinterpret_cast<float4*>(work + l.srec);
   const unsigned pblocks = (unsigned)((np + 255) / 256);
 
   NnHeader h;
@@ -249,6 +377,7 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
   VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   NnGrid g;
   g.M = l.M;
+  double pmax = 0.0;
   for (int a = 0; a < 3; ++a) {
     const double lo = ordered_to_f64(h.bmin[a]), hi = ordered_to_f64(h.bmax[a]);
     if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi))
@@ -258,24 +387,27 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
     g.lo[a] = lo;
     g.w[a] = ext / (double)l.M;
     g.inv_w[a] = (double)l.M / ext;
+    pmax = std::fmax(pmax, std::fmax(std::fabs(lo), std::fabs(hi)));
   }
+  // bound on |float32 distance - exact distance|: each coordinate is rounded to float32 once
+  // (relative 2^-24) on both sides of the subtraction, three components
+  const float err = (float)((qmax + pmax) * 2.5e-7);
   VPS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, sizeof(unsigned) * l.ncell, ctx->stream));
   VPS_HIP_CHECK(ctx, hipMemsetAsync(fill, 0, sizeof(unsigned) * l.ncell, ctx->stream));
   {
     vps_launch_timer tm(ctx, VPS_K_NN_BUILD);
     hipLaunchKernelGGL(nn_count_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np, g, count);
     launch_exclusive_scan(ctx->stream, count, l.ncell, tiles, start);
-    hipLaunchKernelGGL(nn_fill_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np, g, start, fill, spos, sidx);
+    hipLaunchKernelGGL(nn_fill_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np, g, start, fill, srec);
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
-  const long long nq = (long long)nx * nqy * nqz;
-  const long long qblocks = (nq + 255) / 256;
+  const long long qblocks = (long long)nx * ((nqy + NN_TY - 1) / NN_TY) * ((nqz + 63) / 64);
   if (qblocks > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_nn_resample: too many queries for one launch");
   {
     vps_launch_timer tm(ctx, VPS_K_NN_QUERY);
 #define VPS_NNQ(CC)                                                                                  \
-  hipLaunchKernelGGL((nn_query_kernel<F, CC>), dim3((unsigned)qblocks), dim3(256), 0, ctx->stream,   \
-                     spos, sidx, start, g, dqx, dqy, dqz, x0, nx, nqy, nqz, payload, out, nn_idx)
+  hipLaunchKernelGGL((nn_query_kernel<F, CC>), dim3((unsigned)qblocks), dim3(64 * NN_TY), 0, ctx->stream, \
+                     pos, srec, start, g, err, dqx, dqy, dqz, x0, nx, nqy, nqz, payload, out, nn_idx)
     switch (C) {
       case 1: VPS_NNQ(1); break;
       case 3: VPS_NNQ(3); break;
@@ -326,11 +458,16 @@ int vps_nn_resample(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const flo
   VPS_HIP_CHECK(ctx, hipMemcpyAsync(dqy, qy_host, sizeof(double) * nqy, hipMemcpyHostToDevice, ctx->stream));
   VPS_HIP_CHECK(ctx, hipMemcpyAsync(dqz, qz_host, sizeof(double) * nqz, hipMemcpyHostToDevice, ctx->stream));
   char* work = reinterpret_cast<char*>(work_dev);
+  double qmax = 0.0;
+  for (int i = 0; i < nqx; ++i) qmax = std::fmax(qmax, std::fabs(qx_host[i]));
+  for (int i = 0; i < nqy; ++i) qmax = std::fmax(qmax, std::fabs(qy_host[i]));
+  for (int i = 0; i < nqz; ++i) qmax = std::fmax(qmax, std::fabs(qz_host[i]));
+  if (!std::isfinite(qmax)) return vps_fail(ctx, VPS_ERR_ARG, "vps_nn_resample: lattice axes are not finite");
   if (pos_is_f64)
     return nn_run<double>(ctx, reinterpret_cast<const double*>(pos_dev), payload_dev, np, C, x0, nx, nqy,
-                          nqz, dqx, dqy, dqz, out_dev, nn_idx_dev, work);
+                          nqz, dqx, dqy, dqz, qmax, out_dev, nn_idx_dev, work);
   return nn_run<float>(ctx, reinterpret_cast<const float*>(pos_dev), payload_dev, np, C, x0, nx, nqy, nqz,
-                       dqx, dqy, dqz, out_dev, nn_idx_dev, work);
+                       dqx, dqy, dqz, qmax, out_dev, nn_idx_dev, work);
 }
 
 }  // extern "C"

@@ -1,0 +1,62 @@
+"""Two ranks sharing the one GPU of the test box: the real HIP kernels on x-slabs, the
+exchange over gloo (staged through host memory by SlabComm), checked against the oracle.
+RCCL itself needs one GPU per rank, so the nccl backend is exercised by bench.py --gpus N."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vps_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, Np, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "large-velocity-power-spectrum_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vpower import device, synth
+        K = device.default_kernels(0)
+        pos, vel, mass, dens = synth.particles(31, Np, 1.0)
+        pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=device.SlabComm())
+        assert pipe.comm.world == world and pipe.x0 == rank * (N // world)
+        fields = K.deposit_field(K.to_device(pos), K.to_device(vel), K.to_device(dens), N, 1.0,
+                                 pipe.x0, pipe.nx, device.VELOCITY)
+        tab = pipe.spectrum([fields[0], fields[1], fields[2]])
+        np.save(os.path.join(out_dir, f"tab_{rank}.npy"), tab)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N", [(2, 64), (4, 128)])
+def test_two_ranks_one_gpu_hip_kernels(tmp_path, world, N):
+    import torch.multiprocessing as mp
+    from vpower import synth
+    Np = 200000
+    mp.spawn(_worker, args=(world, _free_port(), N, Np, str(tmp_path)), nprocs=world, join=True)
+    pos, vel, mass, dens = synth.particles(31, Np, 1.0)
+    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
+    v, m = orc.vm_from_vec_grid(orc.deposit_to_grid_fast(vec, pos, N, 1.0), 1.0 / N, zero_empty=True)
+    ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, 1.0 / N, "velocity")
+    for r in range(world):
+        tab = np.load(tmp_path / f"tab_{r}.npy")
+        assert np.array_equal(tab[:, 3], ref[:, 3])
+        assert np.allclose(tab[:, 2], ref[:, 2], rtol=2e-5, atol=0)
