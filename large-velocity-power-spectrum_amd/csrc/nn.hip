@@ -14,6 +14,7 @@
 #pragma clang fp contract(off)
 
 #include <cmath>
+#include <cstdlib>
 
 #include "vps_internal.h"
 #include "scan.h"
@@ -114,16 +115,13 @@ __global__ void __launch_bounds__(256)
   srec[slot] = make_float4((float)px, (float)py, (float)pz, __int_as_float((int)i));
 }
 
-// One thread per lattice point; a workgroup owns a tile of 1 x NN_TY x 64 lattice points
-// (z fastest, so results are stored 256 bytes at a time).  The cell columns that rings 0 and
-// 1 of every point of the tile can touch are staged in LDS once (bucket offsets + records),
-// so the per-lane ring search reads LDS instead of issuing scattered global loads; points
-// that need ring 2 or more (rare at about one particle per cell) continue from global memory.
+// One thread per lattice point.  The cell columns that rings 0 and 1 of every point of a
+// workgroup's tile can touch are staged in LDS once (bucket offsets + records); points that
+// need ring 2 or more (rare at about one particle per cell) continue from global memory.
 // Candidates are screened in float32 against a bound that provably keeps every particle
 // whose exact float64 distance could tie or beat the best (err bounds the float32 distance
 // error); survivors are re-evaluated exactly in float64 from the original coordinates, with
 // the lowest-index tie rule.
-constexpr int NN_TY = 4;
 constexpr int NN_MAXCELL = 1024;   // staged bucket-offset entries (4 KiB)
 constexpr int NN_MAXREC = 1024;    // staged records (16 KiB)
 
@@ -154,7 +152,7 @@ __device__ __forceinline__ void nn_consider(const F* __restrict__ pos, const flo
     b.best = d2;
     b.idx = oi;
     // anything with true distance <= sqrt(best) has float32 distance <= sqrt(best)+err
-    const float rb = (float)sqrt(d2) * 1.000001f + err;
+    const float rb = sqrtf((float)d2) * 1.000001f + err;
     b.screen = rb * rb * 1.000001f;
   }
 }
@@ -176,8 +174,23 @@ __device__ __forceinline__ bool nn_done(const NnGrid& g, const int (&c)[3], cons
   return bound > 0.0 && best < bound * bound;
 }
 
+// Workgroup = 4 waves = a 4 x 4 x 16 tile of lattice points; wave w owns the 4 x 4 x 4
+// sub-block at z offset 4w.  All lanes of a wave scan the SAME staged candidates (the union
+// of the cells that rings 0 and 1 of the sub-block can touch): uniform loop bounds, LDS
+// broadcast reads, no divergence outside the rare float64 re-check.
+constexpr int NN_BX = 4, NN_BY = 4, NN_BZ = 16;
+
+__device__ __forceinline__ int wave_min(int v) {
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
 template <typename F, int C>
-__global__ void __launch_bounds__(64 * NN_TY)
+__global__ void __launch_bounds__(256)
     nn_query_kernel(const F* __restrict__ pos, const float4* __restrict__ srec,
                     const unsigned* __restrict__ start, NnGrid g, float err,
                     const double* __restrict__ qx, const double* __restrict__ qy,
@@ -186,41 +199,45 @@ __global__ void __launch_bounds__(64 * NN_TY)
                     int* __restrict__ nn_idx) {
   __shared__ unsigned lstart[NN_MAXCELL];
   __shared__ float4 lrec[NN_MAXREC];
-  __shared__ int range[4];        // min cy, max cy, min cz, max cz over the tile
+  __shared__ int range[6];        // min/max of cx, cy, cz over the tile
   __shared__ unsigned colbase[65];
   __shared__ int staged_flag;
+  __shared__ int lbest[NN_BX * NN_BY * NN_BZ];
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int tz = (nqz + 63) / 64, ty = (nqy + NN_TY - 1) / NN_TY;
+  const int ntz = (nqz + NN_BZ - 1) / NN_BZ, nty = (nqy + NN_BY - 1) / NN_BY;
   const long long tile = blockIdx.x;
-  const int iz = (int)(tile % tz) * 64 + lane;
-  const int iy = (int)((tile / tz) % ty) * NN_TY + wv;
-  const int ix = (int)(tile / ((long long)tz * ty));
-  const bool valid = iz < nqz && iy < nqy;
+  const int tz0 = (int)(tile % ntz) * NN_BZ;
+  const int ty0 = (int)((tile / ntz) % nty) * NN_BY;
+  const int tx0 = (int)(tile / ((long long)ntz * nty)) * NN_BX;
+  const int li = lane >> 4, lj = (lane >> 2) & 3, lk = lane & 3;
+  const int ix = tx0 + li, iy = ty0 + lj, iz = tz0 + wv * 4 + lk;
+  const bool valid = ix < nx && iy < nqy && iz < nqz;
   const int M = g.M;
-  double Q[3] = {qx[x0 + ix], valid ? qy[iy] : qy[0], valid ? qz[iz] : qz[0]};
+  const double Q[3] = {valid ? qx[x0 + ix] : qx[x0], valid ? qy[iy] : qy[0], valid ? qz[iz] : qz[0]};
   const float Qf[3] = {(float)Q[0], (float)Q[1], (float)Q[2]};
   int c[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) c[a] = cell_coord(Q[a], g.lo[a], g.inv_w[a], M);
 
-  if (threadIdx.x == 0) {
-    range[0] = M; range[1] = -1; range[2] = M; range[3] = -1;
+  if (threadIdx.x < 6) range[threadIdx.x] = (threadIdx.x & 1) ? -1 : M;
+  __syncthreads();
+  // per-wave ranges by shuffles, tile ranges by one LDS atomic per wave and bound
+  const int wx0 = wave_min(valid ? c[0] : M), wx1 = wave_max(valid ? c[0] : -1);
+  const int wy0 = wave_min(valid ? c[1] : M), wy1 = wave_max(valid ? c[1] : -1);
+  const int wz0 = wave_min(valid ? c[2] : M), wz1 = wave_max(valid ? c[2] : -1);
+  if (lane == 0 && wx1 >= 0) {
+    atomicMin(&range[0], wx0); atomicMax(&range[1], wx1);
+    atomicMin(&range[2], wy0); atomicMax(&range[3], wy1);
+    atomicMin(&range[4], wz0); atomicMax(&range[5], wz1);
   }
   __syncthreads();
-  if (valid) {
-    atomicMin(&range[0], c[1]);
-    atomicMax(&range[1], c[1]);
-    atomicMin(&range[2], c[2]);
-    atomicMax(&range[3], c[2]);
-  }
-  __syncthreads();
-  // cell columns that rings 0 and 1 of the whole tile can touch (all points share c[0])
-  const int cx0 = max(c[0] - 1, 0), cx1 = min(c[0] + 1, M - 1);
-  const int cy0 = max(range[0] - 1, 0), cy1 = min(range[1] + 1, M - 1);
-  const int cz0 = max(range[2] - 1, 0), cz1 = min(range[3] + 1, M - 1);
-  const int ncx = cx1 - cx0 + 1, ncy = cy1 - cy0 + 1, ncz = cz1 - cz0 + 1;
-  const int ncol = ncx * ncy;
+  // cell columns that rings 0 and 1 of the whole tile can touch
+  const int cx0 = max(range[0] - 1, 0), cx1 = min(range[1] + 1, M - 1);
+  const int cy0 = max(range[2] - 1, 0), cy1 = min(range[3] + 1, M - 1);
+  const int cz0 = max(range[4] - 1, 0), cz1 = min(range[5] + 1, M - 1);
+  const int ncy = cy1 - cy0 + 1, ncz = cz1 - cz0 + 1;
+  const int ncol = (cx1 - cx0 + 1) * ncy;
   const bool fits = range[1] >= 0 && ncol <= 64 && ncol * (ncz + 1) <= NN_MAXCELL;
   if (fits && threadIdx.x < ncol) {
     const long long row = ((long long)(cx0 + threadIdx.x / ncy) * M + (cy0 + threadIdx.x % ncy)) * M;
@@ -240,7 +257,7 @@ __global__ void __launch_bounds__(64 * NN_TY)
   __syncthreads();
   const bool staged = staged_flag != 0;
   if (staged) {
-    for (int col = wv; col < ncol; col += NN_TY) {
+    for (int col = wv; col < ncol; col += 4) {
       const long long row = ((long long)(cx0 + col / ncy) * M + (cy0 + col % ncy)) * M;
       const unsigned g0 = start[row + cz0];
       const unsigned base = colbase[col];
@@ -254,36 +271,48 @@ __global__ void __launch_bounds__(64 * NN_TY)
   NnBest b{INFINITY, INFINITY, 0x7fffffff};
   int r0 = 0;
   bool finished = !valid;
-  if (staged && valid) {
-    for (int r = 0; r <= 1 && !finished; ++r) {
-      const int xlo = max(c[0] - r, 0), xhi = min(c[0] + r, M - 1);
-      const int ylo = max(c[1] - r, 0), yhi = min(c[1] + r, M - 1);
-      for (int cx = xlo; cx <= xhi; ++cx) {
-        const bool xedge = (cx == c[0] - r) || (cx == c[0] + r);
-        for (int cy = ylo; cy <= yhi; ++cy) {
-          const bool edge = xedge || (cy == c[1] - r) || (cy == c[1] + r);
-          const int colrow = ((cx - cx0) * ncy + (cy - cy0)) * (ncz + 1) - cz0;
-          const int nruns = (edge || r == 0) ? 1 : 2;
-          for (int run = 0; run < nruns; ++run) {
-            int z0, z1;
-            if (edge || r == 0) {
-              z0 = max(c[2] - r, 0);
-              z1 = min(c[2] + r, M - 1);
-            } else {
-              z0 = z1 = (run == 0) ? c[2] - r : c[2] + r;
-              if (z0 < 0 || z0 >= M) continue;
-            }
-            const unsigned s = lstart[colrow + z0], e = lstart[colrow + z1 + 1];
-            for (unsigned j = s; j < e; ++j) nn_consider<F>(pos, lrec[j], Q, Qf, err, b);
-          }
+  if (staged && wx1 >= 0) {
+    // this wave's share of the staged region: wave-uniform bounds
+    // (readfirstlane: the values are wave-uniform by construction; telling the compiler keeps
+    // the loop control on the scalar unit)
+    const int sx0 = __builtin_amdgcn_readfirstlane(max(wx0 - 1, 0)), sx1 = __builtin_amdgcn_readfirstlane(min(wx1 + 1, M - 1));
+    const int sy0 = __builtin_amdgcn_readfirstlane(max(wy0 - 1, 0)), sy1 = __builtin_amdgcn_readfirstlane(min(wy1 + 1, M - 1));
+    const int sz0 = __builtin_amdgcn_readfirstlane(max(wz0 - 1, 0)), sz1 = __builtin_amdgcn_readfirstlane(min(wz1 + 1, M - 1));
+    // pass 1, float32 only and branch-free: the smallest float32 squared distance
+    float best32 = INFINITY;
+    for (int cx = sx0; cx <= sx1; ++cx)
+      for (int cy = sy0; cy <= sy1; ++cy) {
+        const int colrow = ((cx - cx0) * ncy + (cy - cy0)) * (ncz + 1) - cz0;
+        const unsigned s = __builtin_amdgcn_readfirstlane(lstart[colrow + sz0]);
+        const unsigned e = __builtin_amdgcn_readfirstlane(lstart[colrow + sz1 + 1]);
+        for (unsigned j = s; j < e; ++j) {
+          const float4 rec = lrec[j];
+          const float fx = Qf[0] - rec.x, fy = Qf[1] - rec.y, fz = Qf[2] - rec.z;
+          const float d2f = (fx * fx + fy * fy) + fz * fz;
+          best32 = d2f < best32 ? d2f : best32;   // (fminf's NaN rules cost a dozen instructions)
         }
       }
+    // pass 2: the exact nearest particle p* satisfies d(p*) <= d(argmin32) <= sqrt(best32)+err,
+    // hence d32(p*) <= sqrt(best32) + 2 err: only those few candidates are re-evaluated in
+    // float64 (nn_consider screens against b.screen)
+    {
+      const float rb = sqrtf(best32) * 1.000001f + 2.f * err;
+      b.screen = rb * rb * 1.000001f;
+    }
+    for (int cx = sx0; cx <= sx1; ++cx)
+      for (int cy = sy0; cy <= sy1; ++cy) {
+        const int colrow = ((cx - cx0) * ncy + (cy - cy0)) * (ncz + 1) - cz0;
+        const unsigned s = __builtin_amdgcn_readfirstlane(lstart[colrow + sz0]);
+        const unsigned e = __builtin_amdgcn_readfirstlane(lstart[colrow + sz1 + 1]);
+        for (unsigned j = s; j < e; ++j) nn_consider<F>(pos, lrec[j], Q, Qf, err, b);
+      }
+    if (valid) {
       bool exhausted;
-      finished = nn_done(g, c, Q, r, b.best, exhausted);
+      finished = nn_done(g, c, Q, 1, b.best, exhausted);
     }
     r0 = 2;
   }
-  // general search from global memory: rings r0, r0+1, ...
+  // general search from global memory: rings r0, r0+1, ... (rare after a staged scan)
   for (int r = r0; r < M && !finished; ++r) {
     const int xlo = max(c[0] - r, 0), xhi = min(c[0] + r, M - 1);
     const int ylo = max(c[1] - r, 0), yhi = min(c[1] + r, M - 1);
@@ -311,18 +340,31 @@ __global__ void __launch_bounds__(64 * NN_TY)
     bool exhausted;
     finished = nn_done(g, c, Q, r, b.best, exhausted);
   }
-  if (!valid) return;
-  const long long nq = (long long)nx * nqy * nqz;
-  const long long q = ((long long)ix * nqy + iy) * nqz + iz;
-  if (nn_idx) nn_idx[q] = b.idx;
-  if (out) {
+  // results leave through LDS so that 16 consecutive z (64 bytes per channel) are stored together
+  lbest[(li * NN_BY + lj) * NN_BZ + wv * 4 + lk] = b.idx;
+  __syncthreads();
+  {
+    const int zz = threadIdx.x & 15, j = (threadIdx.x >> 4) & 3, i = threadIdx.x >> 6;
+    const int ox = tx0 + i, oy = ty0 + j, oz = tz0 + zz;
+    if (ox < nx && oy < nqy && oz < nqz) {
+      const int bi = lbest[(i * NN_BY + j) * NN_BZ + zz];
+      const long long nq = (long long)nx * nqy * nqz;
+      const long long q = ((long long)ox * nqy + oy) * nqz + oz;
+      if (nn_idx) nn_idx[q] = bi;
+      if (out) {
 #pragma unroll
-    for (int ch = 0; ch < C; ++ch) out[(long long)ch * nq + q] = payload[(long long)b.idx * C + ch];
+        for (int ch = 0; ch < C; ++ch) out[(long long)ch * nq + q] = payload[(long long)bi * C + ch];
+      }
+    }
   }
 }
 
 int nn_grid_side(int64_t np) {
-  double m = std::cbrt((double)np);   // about one particle per cell: ring 1 (27 cells) nearly always decides
+  // cells per axis from the particles per cell: 1.5 measured best (sweep 0.7 .. 3) -- the staged
+  // union of cells per 4x4x4 query block grows with smaller cells, the ring-2 fallbacks with larger
+  double ppc = 1.5;
+  if (const char* e = getenv("VPS_EXP_NN_PPC")) ppc = atof(e);
+  double m = std::cbrt((double)np / ppc);
   int M = (int)m;
   if (M < 1) M = 1;
   if (M > 1024) M = 1024;
@@ -401,12 +443,12 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
     hipLaunchKernelGGL(nn_fill_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np, g, start, fill, srec);
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
-  const long long qblocks = (long long)nx * ((nqy + NN_TY - 1) / NN_TY) * ((nqz + 63) / 64);
+  const long long qblocks = (long long)((nx + NN_BX - 1) / NN_BX) * ((nqy + NN_BY - 1) / NN_BY) * ((nqz + NN_BZ - 1) / NN_BZ);
   if (qblocks > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_nn_resample: too many queries for one launch");
   {
     vps_launch_timer tm(ctx, VPS_K_NN_QUERY);
 #define VPS_NNQ(CC)                                                                                  \
-  hipLaunchKernelGGL((nn_query_kernel<F, CC>), dim3((unsigned)qblocks), dim3(64 * NN_TY), 0, ctx->stream, \
+  hipLaunchKernelGGL((nn_query_kernel<F, CC>), dim3((unsigned)qblocks), dim3(256), 0, ctx->stream, \
                      pos, srec, start, g, err, dqx, dqy, dqz, x0, nx, nqy, nqz, payload, out, nn_idx)
     switch (C) {
       case 1: VPS_NNQ(1); break;

@@ -15,3 +15,18 @@ K.timing(True)
 for _ in range(3): K.nn_resample(dpos, payload, (ax, ax, ax), 0, N, out=out)
 t = K.timing_get(); K.timing(False)
 print("N=%d Np=%g: build %.3f ms, query %.3f ms  -> %.3g queries/s" % (N, Np, t["nn_build"][1] / 3, t["nn_query"][1] / 3, N ** 3 / (t["nn_query"][1] / 3 * 1e-3)), flush=True)
+# search only (no payload gather / grid write): index output
+import ctypes as C
+from vpower import _ffi
+idx = K.empty((N, N, N), torch.int32)
+axs = [np.ascontiguousarray(ax, dtype=np.float64)] * 3
+work = K.workspace("nn", K.lib.vps_nn_workspace_bytes(Np, 0))
+def idx_only():
+    K._stream()
+    K._chk(K.lib.vps_nn_resample(K.ctx, K._ptr(dpos), 0, None, Np, 4, _ffi.as_dp(axs[0]), N, _ffi.as_dp(axs[1]), N,
+                                 _ffi.as_dp(axs[2]), N, 0, N, None, K._ptr(idx), K._ptr(work)))
+for _ in range(2): idx_only()
+K.timing(True)
+for _ in range(3): idx_only()
+t = K.timing_get(); K.timing(False)
+print("   index only: query %.3f ms" % (t["nn_query"][1] / 3), flush=True)
