@@ -164,7 +164,15 @@ struct PlanInfo {
   static_assert(RL % R0 == 0 && RL % R1 == 0 && RL % R2 == 0, "radix must divide RL");
 };
 
-__device__ __forceinline__ int padidx(int p) { return p + (p >> 5); }
+// Position of element p inside a line's LDS exchange buffer: one pad slot per 32 elements.
+// (Measured alternative: the XOR swizzle p ^ ((p >> A) & 15) makes every exchange access of the
+// 512..4096-point plans bank-conflict free on paper, but its per-access address arithmetic
+// costs ~30 VGPRs, drops the x pass from 3 to 2 waves/SIMD and ran 20-60 % slower at
+// N = 1024/2048, with no measurable gain in the z/y passes: the exchanges are not the limiter.)
+template <int NC>
+__device__ __forceinline__ int padidx(int p) {
+  return p + (p >> 5);
+}
 
 // Transposed tile image [k][t] with pitch T and an XOR swizzle of t, so that both the
 // column-wise writes (16 consecutive k, one t) and the row-wise reads (one k, all t)
@@ -182,7 +190,7 @@ __device__ __forceinline__ void lds_load_stage(cf (&v)[RL], const cf* line, int 
 #pragma unroll
   for (int m = 0; m < NB; ++m) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[m * R + r] = line[padidx(l + L * m + r * (NC / R))];
+    for (int r = 0; r < R; ++r) v[m * R + r] = line[padidx<NC>(l + L * m + r * (NC / R))];
   }
 }
 
@@ -209,13 +217,28 @@ __device__ __forceinline__ void lds_store_stage(const cf (&v)[RL], cf* line, int
     const int k = j & (NS - 1);
     const int j0 = (j - k) * R + k;
 #pragma unroll
-    for (int r = 0; r < R; ++r) line[padidx(j0 + r * NS)] = v[m * R + r];
+    for (int r = 0; r < R; ++r) line[padidx<NC>(j0 + r * NS)] = v[m * R + r];
+  }
+}
+
+// Exchange synchronisation.  When a line's L lanes live inside one wave (L <= 64, lines never
+// straddle waves) the stage exchanges only need wave-level ordering: a wave's LDS operations
+// execute in issue order, so a compiler fence is enough and the waves of a workgroup run
+// decoupled.  Otherwise a workgroup barrier.
+template <bool WAVE>
+__device__ __forceinline__ void exchange_sync() {
+  if constexpr (WAVE) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
   }
 }
 
 // Runs stages 1.. (stage 0 inputs already in v).  On return v holds the spectrum:
 // v[m*RLAST + r] = F[l + L*m + r*NC/RLAST].
-template <int NC>
+template <int NC, bool WAVE = false>
 __device__ __forceinline__ void fft_from_regs(cf (&v)[PlanInfo<NC>::RL], cf* line, const cf* tw,
                                               int l) {
   typedef PlanInfo<NC> PI;
@@ -223,13 +246,13 @@ __device__ __forceinline__ void fft_from_regs(cf (&v)[PlanInfo<NC>::RL], cf* lin
   twiddle_butterfly<NC, L, RL, PI::R0, 1>(v, tw, l);
   if constexpr (PI::R1 > 1) {
     lds_store_stage<NC, L, RL, PI::R0, 1>(v, line, l);
-    __syncthreads();
+    exchange_sync<WAVE>();
     lds_load_stage<NC, L, RL, PI::R1>(v, line, l);
     twiddle_butterfly<NC, L, RL, PI::R1, PI::NS1>(v, tw, l);
     if constexpr (PI::R2 > 1) {
-      __syncthreads();
+      exchange_sync<WAVE>();
       lds_store_stage<NC, L, RL, PI::R1, PI::NS1>(v, line, l);
-      __syncthreads();
+      exchange_sync<WAVE>();
       lds_load_stage<NC, L, RL, PI::R2>(v, line, l);
       twiddle_butterfly<NC, L, RL, PI::R2, PI::NS2>(v, tw + PI::TW1, l);
     }
@@ -425,7 +448,10 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   const long long ntiles = (p.nlines + T - 1) / T;
   // PAIR (FAST path on whole ky ranges): a tile holds T/2 lines ky and their mirrors N-ky,
   // which share every s with them, so one lane bins four modes (+-kx, +-ky) per step.
-  constexpr bool CANPAIR = FAST && (T >= 2) && (NC >= T) && (NC % T == 0);
+  // wave-level synchronisation of everything line-local (exchanges, |F|^2 image)
+  constexpr bool WSYNC = (L <= 64) && (64 % L == 0);
+  // pairs are adjacent lines (t, t^1): with at least two lines per wave a pair never leaves its wave
+  constexpr bool CANPAIR = FAST && (T >= 2) && (NC >= T) && (NC % T == 0) && (!WSYNC || L <= 32);
   const bool pair = CANPAIR && p.pair;
   constexpr int TH = (T >= 2) ? T / 2 : 1;
   // tile -> this lane's line, and the loads of its stage-0 inputs
@@ -438,17 +464,17 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   cf v[RL];
   auto locate_line = [&](long long tile) {
     li = tile * T + t;       // local line index
-    mirrored = false;        // this line is the N-ky partner of line t - TH
-    has_partner = false;     // line t + TH holds this line's N-ky partner
+    mirrored = false;        // this line is the N-ky partner of line t - 1
+    has_partner = false;     // line t + 1 holds this line's N-ky partner
     if (pair) {
       constexpr long long tiles_per_plane = (NC / T) > 0 ? (NC / T) : 1;
       const long long plane = tile / tiles_per_plane;
       const int q = (int)(tile % tiles_per_plane);
-      const int ky_a = q * TH + (t % TH);
-      const int ky = (t < TH) ? ky_a : (ky_a == 0 ? NC / 2 : NC - ky_a);
+      const int ky_a = q * TH + (t >> 1);
+      const int ky = ((t & 1) == 0) ? ky_a : (ky_a == 0 ? NC / 2 : NC - ky_a);
       li = plane * NC + ky;
-      mirrored = (t >= TH) && (ky_a != 0);
-      has_partner = (t < TH) && (ky_a != 0);
+      mirrored = ((t & 1) == 1) && (ky_a != 0);
+      has_partner = ((t & 1) == 0) && (ky_a != 0);
     }
     live = li < p.nlines;
     if constexpr (MODE == 0) {
@@ -488,8 +514,8 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
     const bool live_cur = live, mirrored_cur = mirrored, partner_cur = has_partner;
     const double k2y_cur = k2y, k2z_cur = k2z;
     const unsigned wz_cur = wz;
-    __syncthreads();  // previous tile's readers are done with the line buffers
-    fft_from_regs<NC>(v, line, tw, l);
+    exchange_sync<WSYNC>();  // previous tile's readers are done with the line buffers
+    fft_from_regs<NC, WSYNC>(v, line, tw, l);
     if constexpr (MODE == 1) {
       if (live_cur) {
         cf* o = p.out + li_cur * (long long)NC;
@@ -512,14 +538,14 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
       // lane accumulates each run of equal bins in registers and issues one LDS float64
       // atomic per run, and the lanes of a wave-instruction hit different bins.
       float* pw = reinterpret_cast<float*>(line);
-      if constexpr (PI::R1 > 1) __syncthreads();  // last exchange fully consumed
+      if constexpr (PI::R1 > 1) exchange_sync<WSYNC>();  // last exchange fully consumed
       constexpr int CH = FAST ? H : RL;              // chunk length; one pad word per chunk
 #pragma unroll
       for (int i = 0; i < RL; ++i) {
         const int k = out_index<NC>(l, i);
         pw[k + k / CH] = v[i].x * v[i].x + v[i].y * v[i].y;
       }
-      __syncthreads();
+      exchange_sync<WSYNC>();
       // v is dead from here on: start fetching the next tile's lines so that the loads are
       // in flight while this tile is binned
       if (tile + gridDim.x < ntiles) {
@@ -530,8 +556,8 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
         if (live_cur && !mirrored_cur) {
           const unsigned w = wz_cur * (partner_cur ? 2u : 1u);
           const float wf = (float)wz_cur;
-          // the partner line's |F|^2 image sits TH line buffers further on
-          constexpr int POFF = TH * PI::PITCH * 2;
+          // the partner line's |F|^2 image is the next line buffer
+          constexpr int POFF = PI::PITCH * 2;
           const float* mine = pw + l * (H + 1);                        // kx = l*H + i
           const float* mirr = pw + (NC + NC / H - 1) - l * (H + 1);    // NC-kx for i >= 1 at mirr[-i]
           // Every |kx| is binned independently (no chain between the LDS reads): the edges
