@@ -339,6 +339,54 @@ def test_config1_full_size_against_oracle():
     assert np.allclose(tab[:, 1], ref[:, 1], rtol=PSUM_RTOL, atol=0)
 
 
+# ------------------------------------------------------------------- edge cases ----
+def test_edge_cases_empty_single_and_errors(K):
+    from vpower import device, interp, _ffi
+    N, L = 16, 1.0
+    # no particles: every cell is written (zeros), spectrum is identically zero with full counts
+    empty = K.deposit_field(K.empty((0, 3), torch.float32), K.empty((0, 3), torch.float32),
+                            K.empty((0,), torch.float32), N, L, 0, N, device.VELOCITY)
+    assert empty.shape == (3, N, N, N) and float(empty.abs().max()) == 0.0
+    pipe = device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False))
+    tab = pipe.finish(*pipe.accumulate([empty[0], empty[1], empty[2]]))
+    assert np.all(tab[:, 2] == 0) and list(tab[:, 3].astype(int)) == [18, 62, 98, 210, 350, 450, 602, 687]
+    # one particle exactly on the upper box face wraps to cell 0 (periodic rule of interp.py:1011)
+    g = interp.deposit_to_grid(np.array([2.0]), np.array([[1.0, 0.5, 0.999999]]), N, L)
+    assert g[0, 8, 15] == 2.0 and g.sum() == 2.0
+    # many particles in ONE cell (bucket far larger than a workgroup; float sums of small integers are exact)
+    pos = np.full((100000, 3), 0.53, dtype=np.float32)
+    g = interp.deposit_to_grid(np.ones(100000), pos, N, L)
+    assert g[8, 8, 8] == 100000.0 and g.sum() == 100000.0
+    # a single particle is everybody's nearest neighbour
+    idx = interp.nn_index(np.array([[0.3, 0.3, 0.3]]), (np.linspace(0, 1, 5),) * 3)
+    assert idx.shape == (5, 5, 5) and not idx.any()
+    # unsupported sizes and bad arguments fail loudly, with the library's message
+    with pytest.raises(Exception):
+        device.PowerPipeline(500, L, kernels=K, comm=device.SlabComm(enabled=False))
+    with pytest.raises(_ffi.VpsError, match="slab"):
+        K.deposit(K.zeros((4, 3), torch.float32), K.zeros((4, 1), torch.float32), N, L, 8, 16)
+    with pytest.raises(_ffi.VpsError, match="contiguous|float32"):
+        K.fft_zy(K.zeros((N, N, N), torch.float64), N, N)
+    with pytest.raises(_ffi.VpsError, match="C=2"):
+        K.deposit(K.zeros((4, 3), torch.float32), K.zeros((4, 2), torch.float32), N, L, 0, N)
+
+
+def test_float64_positions_through_fused_deposit(K):
+    from vpower import device
+    rng = np.random.default_rng(12)
+    N, L, Np = 32, 2.5, 40000
+    pos = rng.random((Np, 3)) * L
+    vel = rng.standard_normal((Np, 3)).astype(np.float32)
+    rho = np.exp(rng.standard_normal(Np)).astype(np.float32)
+    out = K.deposit_field(K.to_device(pos), K.to_device(vel), K.to_device(rho), N, L, 0, N, device.VM).cpu().numpy()
+    vec = orc.density_velocity_vector(vel.astype(np.float64), rho.astype(np.float64))
+    v, m = orc.vm_from_vec_grid(orc.deposit_to_grid(vec, pos, N, L), L / N, zero_empty=True)
+    assert np.allclose(out[:3].transpose(1, 2, 3, 0), v, rtol=2e-5, atol=1e-6)
+    assert np.allclose(out[3], m, rtol=2e-5, atol=0)
+    e = K.deposit_field(K.to_device(pos), K.to_device(vel), K.to_device(rho), N, L, 0, N, device.ENERGY).cpu().numpy()
+    assert np.allclose(e[0], orc.kinetic_energy_field(v[..., 0], v[..., 1], v[..., 2], m), rtol=1e-4, atol=1e-9)
+
+
 # ------------------------------------------------ slab / segment layout, long lines ----
 @pytest.mark.parametrize("N,G", [(64, 2), (128, 4), (256, 8)])
 def test_emulated_slab_ranks_on_one_gpu(K, N, G):
