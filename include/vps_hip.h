@@ -81,6 +81,15 @@ int vps_timing_get(vps_ctx* ctx, int kind, int64_t* launches, double* total_ms);
 /* per-launch durations (ms) of kind `kind` in launch order; *n_out = how many exist */
 int vps_timing_list(vps_ctx* ctx, int kind, double* ms_out, int64_t cap, int64_t* n_out);
 
+/* ---- stage A0: particle preprocessing ----------------------------------- */
+/* In place on the device: coords[:,a] -= min(coords[:,a]) (scripts/parallel_optimized.py:280-282,
+ * vpower/interp.py:169-175; exact in the dtype of pos) and v[:,a] -= sum(m v[:,a])/sum(m)
+ * (script:285-289, interp.py:178-182; mean accumulated in float64, subtracted as float32).
+ * min_out_host[3] / bulk_out_host[3] (may be NULL) receive what was subtracted.  Blocks. */
+int vps_preprocess(vps_ctx* ctx, void* pos_dev, int pos_is_f64, float* vel_dev,
+                   const float* mass_dev, int64_t np, int shift_to_origin,
+                   int remove_bulk_velocity, double* min_out_host, double* bulk_out_host);
+
 /* ---- stage A1: nearest-grid-point deposition ---------------------------- */
 /* Replaces deposit_to_grid (vpower/interp.py:996-1015).
  * Cell index per axis = int((pos // Lcell) % N) evaluated with numpy's

@@ -116,21 +116,17 @@ def velocity_spectrum(coords, mass, velocity, ntot, ltot, comm=None, kernels=Non
     (nbins,4) table that rank 0 saves."""
     import torch
     from vpower import device
-    coords = np.array(coords, copy=True)
-    velocity = np.array(velocity, copy=True)
-    for a in range(3):
-        coords[:, a] -= np.min(coords[:, a])
-    if remove_bulk_velocity:
-        M = np.sum(mass)
-        for a in range(3):
-            velocity[:, a] -= np.sum(mass * velocity[:, a]) / M
     k = kernels if kernels is not None else device.default_kernels()
     pipe = device.PowerPipeline(ntot, ltot, kernels=k, comm=comm, flavour="script")
     lcell = ltot / ntot
     ax = np.array([i * lcell for i in range(ntot)], dtype=np.float32).astype(np.float64)
+    # preprocessing of :280-291 on the device, in the snapshot's coordinate dtype
+    c = np.asarray(coords)
+    pos = k.to_device(c if c.dtype == np.float32 else c.astype(np.float64))
+    vel = k.to_device(np.asarray(velocity), torch.float32)
+    k.preprocess(pos, vel, k.to_device(np.asarray(mass), torch.float32), True, remove_bulk_velocity)
     # Annoy holds float32 coordinates (add_item, :308): search them as float32
-    pos = k.to_device(np.asarray(coords, dtype=np.float32))
-    vel = k.to_device(np.asarray(velocity, dtype=np.float32))
+    pos = pos.to(torch.float32)
     grid, _ = k.nn_resample(pos, vel, (ax, ax, ax), pipe.x0, pipe.nx)
     psum, ns = pipe.accumulate([grid[0], grid[1], grid[2]])
     tab = pipe.finish(psum, ns)

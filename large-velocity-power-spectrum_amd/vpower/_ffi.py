@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.environ.get("VPS_LIB_PATH") or os.path.join(_HERE, "libvps_hip.so")  # override: experiments only
-SOURCES = ("api.hip", "deposit.hip", "nn.hip", "fft.hip", "hist.hip")
+SOURCES = ("api.hip", "deposit.hip", "nn.hip", "fft.hip", "hist.hip", "preprocess.hip")
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics")
 
 # every symbol include/vps_hip.h declares: (name, restype, argtypes)
@@ -39,6 +39,7 @@ SYMBOLS = (
     ("vps_timing_reset", C.c_int, (_vp,)),
     ("vps_timing_get", C.c_int, (_vp, C.c_int, C.POINTER(_i64), _dp)),
     ("vps_timing_list", C.c_int, (_vp, C.c_int, _dp, _i64, C.POINTER(_i64))),
+    ("vps_preprocess", C.c_int, (_vp, _vp, C.c_int, _vp, _vp, _i64, C.c_int, C.c_int, _dp, _dp)),
     ("vps_cell_index", C.c_int, (_vp, _vp, C.c_int, _i64, C.c_int, C.c_double, _vp)),
     ("vps_deposit_workspace_bytes", C.c_size_t, (_i64, C.c_int, C.c_int, C.c_int)),
     ("vps_deposit_ngp", C.c_int, (_vp, _vp, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_double,

@@ -194,6 +194,18 @@ class HipKernels:
         return buf[: n.value]
 
     # -- stage A --------------------------------------------------------------
+    def preprocess(self, pos, vel, mass, shift_to_origin=True, remove_bulk_velocity=True):
+        """In place: shift positions to the origin, remove the mass-weighted bulk velocity.
+        Returns (min[3], bulk[3]) that were subtracted."""
+        self._stream()
+        mn, bv = np.zeros(3), np.zeros(3)
+        self._chk(self.lib.vps_preprocess(self.ctx, self._ptr(pos), self._pos_kind(pos),
+                                          self._ptr(vel, torch.float32) if vel is not None else None,
+                                          self._ptr(mass, torch.float32) if mass is not None else None,
+                                          pos.shape[0], 1 if shift_to_origin else 0,
+                                          1 if remove_bulk_velocity else 0, _ffi.as_dp(mn), _ffi.as_dp(bv)))
+        return mn, bv
+
     @staticmethod
     def _pos_kind(pos):
         if pos.dtype == torch.float32:

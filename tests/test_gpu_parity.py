@@ -91,6 +91,23 @@ def test_deposit_api_and_integer_conservation():
     assert np.all(interp.deposit_to_grid(np.zeros(0), np.zeros((0, 3)), N, L) == 0)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_preprocess_matches_reference_rules(K, dtype):
+    rng = np.random.default_rng(21)
+    Np = 300001
+    pos = (rng.random((Np, 3)) * 3.0 + 0.25).astype(dtype)
+    vel = (rng.standard_normal((Np, 3)) + 0.3).astype(np.float32)
+    mass = np.exp(rng.standard_normal(Np)).astype(np.float32)
+    dp, dv = K.to_device(pos), K.to_device(vel)
+    mn, bv = K.preprocess(dp, dv, K.to_device(mass))
+    rp, rv = orc.preprocess_script(pos, mass, vel)
+    assert np.array_equal(dp.cpu().numpy(), rp)                       # min and subtraction are exact
+    assert np.array_equal(mn, pos.min(axis=0).astype(np.float64))
+    assert np.allclose(dv.cpu().numpy(), rv, rtol=0, atol=2e-6)        # float32 pairwise sum vs float64
+    ref_bulk = (mass[:, None].astype(np.float64) * vel).sum(0) / mass.astype(np.float64).sum()
+    assert np.allclose(bv, ref_bulk, rtol=1e-6)
+
+
 # ------------------------------------------------------------------ stage A2 ----
 @pytest.mark.parametrize("tag", ["n16", "n32"])
 def test_nn_index_golden_library_lattice(tag):
