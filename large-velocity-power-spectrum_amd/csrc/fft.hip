@@ -732,6 +732,7 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
   // 1024-point complex lines: 16-line tiles (128-byte segments, one 1024-thread workgroup per
   // CU) measured 13 % faster than 8-line tiles; for the packed-real 1024-point z pass the
   // 8-line tiles with XCD-paired placement are faster.
+  // (4-line tiles with four-way XCD grouping were slower at 2048: 2.59 vs 2.25 ms.)
   constexpr int T = (NC == 1024 && !REAL) ? 16 : transpose_T<NC>();
   typedef PlanInfo<NC> PI;
   const size_t lds = transpose_lds_bytes<NC, T>();
@@ -766,10 +767,8 @@ int launch_x(vps_ctx* ctx, const XParams& p_in, bool fast = false) {
   if (lds > 64 * 1024)
     VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (const char* e = getenv("VPS_EXP_XLDS_PAD")) lds += (size_t)atol(e);   // experiments only
   const long long ntiles = (p.nlines + T - 1) / T;
   long long per_cu = (long long)(ctx->lds_per_cu / (lds ? lds : 1));
-  if (const char* e = getenv("VPS_EXP_XPERCU")) per_cu = atol(e);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
   long long grid = (long long)ctx->num_cu * per_cu;

@@ -362,8 +362,7 @@ __global__ void __launch_bounds__(256)
 int nn_grid_side(int64_t np) {
   // cells per axis from the particles per cell: 1.5 measured best (sweep 0.7 .. 3) -- the staged
   // union of cells per 4x4x4 query block grows with smaller cells, the ring-2 fallbacks with larger
-  double ppc = 1.5;
-  if (const char* e = getenv("VPS_EXP_NN_PPC")) ppc = atof(e);
+  const double ppc = 1.5;
   double m = std::cbrt((double)np / ppc);
   int M = (int)m;
   if (M < 1) M = 1;
