@@ -6,8 +6,8 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one full pass of the path over one synthetic particle set already resident in
-HBM: NGP deposit of [rho v, rho] through per-brick LDS buckets with v = rho v / rho applied
-in the brick epilogue (count, scan, scatter, accumulate+write), three z/y FFT passes + all-to-all (N>1) + x pass with fused |F|^2 shell binning, shell all-reduce,
+HBM: NGP deposit of [rho v, rho] into per-pencil buckets (rank, scan, scatter), one fused
+kernel that accumulates each pencil in LDS, forms v = rho v / rho and z-transforms it, three y passes + all-to-all (N>1) + x pass with fused |F|^2 shell binning, shell all-reduce,
 download of the (nbins,) sums, P(k) table.  Workload: BASELINE.json configs[1]
 (512^3 grid, 1e7 particles, velocity P(k), nearest-grid-point deposition); with N>1 the SAME
 grid is slab-decomposed over the N GPUs (strong scaling, one RCCL all-to-all per field).
@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2", help="C1..C5 of vpower.synth.CONFIGS (grid, particles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="separate deposit and z-pass kernels (grid through HBM)")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra instrumented steps for the roofline")
     args = ap.parse_args()
 
@@ -105,13 +106,25 @@ def main():
     G = world
     nkz, nky = N // 2 // G, N // G
 
+    fused = K.fused_supported(N, device.VELOCITY) and not args.unfused
+    if fused:
+        spec3 = K.empty((3, N // 2, N, nx), torch.complex64)
+        nyq3 = K.empty((3, N, nx), torch.complex64)
+
     def step():
-        K.deposit_field(dpos, dvel, drho, N, L, x0, nx, device.VELOCITY, out=grid)
         psum.zero_()
         nsample.zero_()
         K.set_binning(*pipe._binning)
+        if fused:
+            # deposit + v = rho v / rho + z pass in one kernel (pencil buckets), then the y passes
+            K.deposit_fft_zy(dpos, dvel, drho, N, L, x0, nx, device.VELOCITY, spec=spec3, nyq=nyq3)
+        else:
+            K.deposit_field(dpos, dvel, drho, N, L, x0, nx, device.VELOCITY, out=grid)
         for c in range(3):
-            s, q = K.fft_zy(grid[c], N, nx, spec=spec, nyq=nyq)
+            if fused:
+                s, q = spec3[c], nyq3[c]
+            else:
+                s, q = K.fft_zy(grid[c], N, nx, spec=spec, nyq=nyq)
             s = comm.all_to_all(s)
             q = comm.all_to_all(q)
             K.fft_x_bin(s, N, nkz * N, 0, rank * nkz, G, nkz * N * nx, psum, nsample, count=(c == 0))
@@ -151,24 +164,31 @@ def main():
     # y and x launches alternate main / Nyquist-plane; the main launch is the big one
     main_y, main_x = per["fft_y"][0::2], per["fft_x"][0::2]
     NH = N // 2
+    mean = lambda v: float(np.mean(v)) if len(v) else 0.0
+    if fused:
+        # one pencil launch per step: bucket records in (3 passes), three z-transformed fields out
+        z_bytes = 3 * 8.0 * nx * N * (NH + 1) + 3 * 20.0 * Np / world
+        z_per_field = z_bytes / 3
+    else:
+        z_bytes = 4.0 * nx * N * N + 8.0 * nx * N * (NH + 1)
+        z_per_field = z_bytes
     alg_bytes = {   # algorithmic HBM bytes per main launch (DESIGN.md "Kernels")
-        "fft_z": 4.0 * nx * N * N + 8.0 * nx * N * (NH + 1),
+        "fft_z": z_bytes,
         "fft_y": 16.0 * nx * N * NH,
         "fft_x": 8.0 * nkz * N * N,
-        "deposit": 28.0 * Np + 0.0,      # particle reads (grid RMW is data dependent)
     }
-    avg_ms = {"fft_z": float(np.mean(per["fft_z"])), "fft_y": float(np.mean(main_y)),
-              "fft_x": float(np.mean(main_x)),
-              # whole deposit stage: count+scan+scatter ("deposit") and brick accumulate+write ("algebra")
-              "deposit": float(np.mean(per["deposit"])) + float(np.mean(per["algebra"]))}
+    avg_ms = {"fft_z": mean(per["fft_z"]), "fft_y": mean(main_y), "fft_x": mean(main_x),
+              # gridding stage: rank+scan+scatter ("deposit") and, unfused, brick accumulate+write ("algebra");
+              # fused, the accumulation lives inside the z-pass launch
+              "deposit": mean(per["deposit"]) + mean(per["algebra"])}
     step_kernel_ms = {k: v[1] / nst for k, v in tim.items() if v[0]}
     dom = max(("fft_z", "fft_y", "fft_x"), key=lambda k: step_kernel_ms.get(k, 0.0))
     ach = alg_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
     fft_ms = sum(step_kernel_ms.get(k, 0.0) for k in ("fft_z", "fft_y", "fft_x"))
-    fft_bytes = 3 * (alg_bytes["fft_z"] + 16.0 * nx * N * (NH + 1) + 8.0 * (nkz * N + nky) * N)
+    fft_bytes = 3 * (z_per_field + 16.0 * nx * N * (NH + 1) + 8.0 * (nkz * N + nky) * N)
     traffic = None
     tr_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tr_path) and args.config == "C2" and world == 1:
+    if os.path.exists(tr_path) and args.config == "C2" and world == 1 and (dom != "fft_z" or not fused):
         try:
             traffic = json.load(open(tr_path)).get(dom)
         except Exception:
@@ -184,6 +204,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d^3 grid, %d particles, velocity P(k), NGP deposit, library binning"
                                % (args.config, N, Np), "grid": N, "particles": Np,
+                   "path": "fused deposit+z pass (pencil buckets)" if fused else "deposit -> grid -> z pass",
                    "parallelism": "x-slab x%d, 1 all-to-all/field" % world},
         "particles_per_s": Np / (avg_ms["deposit"] * 1e-3) if avg_ms["deposit"] > 0 else None,
         "fft_cells_per_s": cells / (fft_ms * 1e-3) / 1.0 if fft_ms > 0 else None,

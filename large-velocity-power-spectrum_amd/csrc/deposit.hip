@@ -173,9 +173,9 @@ __device__ __forceinline__ void algebra_cell(float a, float b, float c, float rh
   if (flags & VPS_FLAG_INPUT_IS_VM) {
     vx = a; vy = b; vz = c; m = rho;
   } else {
-    // one reciprocal per cell (about 1 ulp; the result is compared at 2e-5 with a float64
-    // reference) instead of three IEEE divisions
-    const float inv = rho != 0.f ? __frcp_rn(rho) : 0.f;
+    // one hardware reciprocal per cell (v_rcp_f32, 1 ulp; the result is compared at 2e-5 with a
+    // float64 reference) instead of three IEEE divisions (about a dozen instructions each)
+    const float inv = rho != 0.f ? __builtin_amdgcn_rcpf(rho) : 0.f;
     vx = a * inv;
     vy = b * inv;
     vz = c * inv;
@@ -386,6 +386,20 @@ Bricks make_bricks(int N, int x0, int nx, int C) {
   return b;
 }
 
+// pencil buckets of the fused deposit -> z-pass path: (x, TP y-lines, all z)
+Bricks make_pencils(int N, int x0, int nx, int TP) {
+  Bricks b;
+  b.N = N; b.x0 = x0; b.nx = nx;
+  b.bx = 1; b.by = TP; b.bz = N;
+  b.nbx = nx; b.nby = N / TP; b.nbz = 1;
+  b.cells = TP * N;
+  b.pow2 = 1;
+  b.sy = b.sz = 0;
+  while ((1 << b.sy) < b.by) ++b.sy;
+  while ((1 << b.sz) < b.bz) ++b.sz;
+  return b;
+}
+
 struct DepLayout {
   size_t count, start, tiles, keys, ranks, records, total;
   long long nbricks;
@@ -455,6 +469,36 @@ int deposit_run(vps_ctx* ctx, const void* pos_v, const float* payload, const flo
 #undef VPS_BRICK
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
+  return VPS_OK;
+}
+
+// rank -> scan -> scatter of [rho v, rho] records into the buckets `b`; returns the layout used
+template <typename F>
+int sort_rhov_records(vps_ctx* ctx, const F* pos, const float* vel, const float* rho, int64_t np, int N,
+                      double Lbox, const Bricks& b, char* work, DepLayout* lay) {
+  const F lcell = (F)(Lbox / (double)N);
+  const F nsz = (F)N;
+  const DepLayout l = dep_layout(np, 4, b);
+  unsigned* count = reinterpret_cast<unsigned*>(work + l.count);
+  unsigned* start = reinterpret_cast<unsigned*>(work + l.start);
+  unsigned* tiles = reinterpret_cast<unsigned*>(work + l.tiles);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(work + l.keys);
+  unsigned* ranks = reinterpret_cast<unsigned*>(work + l.ranks);
+  unsigned* records = reinterpret_cast<unsigned*>(work + l.records);
+  VPS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, sizeof(unsigned) * l.nbricks, ctx->stream));
+  const unsigned pblocks = (unsigned)((np + 255) / 256);
+  {
+    vps_launch_timer tm(ctx, VPS_K_DEPOSIT);
+    if (np > 0)
+      hipLaunchKernelGGL(brick_rank_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np,
+                         lcell, nsz, b, count, keys, ranks);
+    launch_exclusive_scan(ctx->stream, count, l.nbricks, tiles, start);
+    if (np > 0)
+      hipLaunchKernelGGL((brick_scatter_kernel<4, true>), dim3(pblocks), dim3(256), 0, ctx->stream, keys, ranks,
+                         vel, rho, (long long)np, (unsigned)b.cells, start, records);
+  }
+  VPS_HIP_CHECK(ctx, hipGetLastError());
+  *lay = l;
   return VPS_OK;
 }
 
@@ -534,6 +578,44 @@ int vps_deposit_field(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const f
                                                                nx, quantity, flags, fields_dev, work_dev)
                     : deposit_run<float, 4, true, EPI_ALGEBRA>(ctx, pos_dev, vel_dev, rho_dev, np, N, Lbox, x0,
                                                               nx, quantity, flags, fields_dev, work_dev);
+}
+
+int vps_deposit_fft_zy_supported(vps_ctx* ctx, int N, int quantity) {
+  if (!ctx) return 0;
+  return (quantity == VPS_VELOCITY || quantity == VPS_MOMENTUM) && vps_pencil_supported(ctx, N) ? 1 : 0;
+}
+
+size_t vps_deposit_fft_zy_workspace_bytes(int64_t np, int N, int nx) {
+  if (np < 0 || N < 16 || nx < 1) return 0;
+  const Bricks b = make_pencils(N, 0, nx, vps_pencil_tp());
+  const size_t sort = dep_layout(np, 4, b).total;
+  const size_t images = 3 * ((size_t)nx * (N / 2) * N + (size_t)nx * N) * sizeof(float2);
+  return sort + images;
+}
+
+int vps_deposit_fft_zy(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
+                       const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx, int quantity,
+                       int flags, void* spec_dev, void* nyq_dev, void* work_dev) {
+  if (!ctx) return VPS_ERR_ARG;
+  int rc = check_deposit_args(ctx, "vps_deposit_fft_zy", np, N, Lbox, x0, nx);
+  if (rc) return rc;
+  if (!vps_deposit_fft_zy_supported(ctx, N, quantity))
+    return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_deposit_fft_zy: N=%d quantity=%d not supported by the fused path", N, quantity);
+  if (!spec_dev || !nyq_dev || !work_dev || (np > 0 && (!pos_dev || !vel_dev || !rho_dev)))
+    return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_fft_zy: null buffer");
+  const Bricks b = make_pencils(N, x0, nx, vps_pencil_tp());
+  char* work = reinterpret_cast<char*>(work_dev);
+  DepLayout l;
+  rc = pos_is_f64 ? sort_rhov_records<double>(ctx, reinterpret_cast<const double*>(pos_dev), vel_dev, rho_dev, np, N, Lbox, b, work, &l)
+                  : sort_rhov_records<float>(ctx, reinterpret_cast<const float*>(pos_dev), vel_dev, rho_dev, np, N, Lbox, b, work, &l);
+  if (rc) return rc;
+  const double lc = Lbox / (double)N;
+  const int bug = (quantity == VPS_MOMENTUM) && (flags & VPS_FLAG_REFERENCE_MOMENTUM_BUG);
+  const int chan[3] = {0, bug ? 0 : 1, bug ? 0 : 2};
+  return vps_fft_pencil_zy(ctx, N, nx, reinterpret_cast<const unsigned*>(work + l.records),
+                           reinterpret_cast<const unsigned*>(work + l.start), 3, chan,
+                           quantity == VPS_VELOCITY ? 1 : 0, (float)(lc * lc * lc), spec_dev, nyq_dev,
+                           work + l.total);
 }
 
 int vps_density_velocity_vector(vps_ctx* ctx, const float* vel_dev, const float* rho_dev, int64_t np,

@@ -348,7 +348,9 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
     }
   }
   __syncthreads();  // twiddle image visible
-  fft_from_regs<NC>(v, buf + t * PI::PITCH, tw, l);
+  // a line's lanes sit in one wave when L divides 64: stage exchanges then need no workgroup barrier
+  constexpr bool WSYNC = (L <= 64) && (64 % L == 0);
+  fft_from_regs<NC, WSYNC>(v, buf + t * PI::PITCH, tw, l);
   __syncthreads();  // every lane done with the per-line buffers
   // transposed image [k][t]
 #pragma unroll
@@ -388,6 +390,170 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
       if (a0 + tt < p.A) out[(long long)k * p.out_ok + tt] = res;
     }
   }
+}
+
+// ------------------------------------------------------------------------------
+// Fused deposit + field algebra + z pass ("pencil" kernel).  A pencil is the TP z-lines
+// (x, y0..y0+TP-1, all z) that one z-pass tile transforms.  The deposit stage has sorted
+// the particle records {cell-in-pencil, rho vx, rho vy, rho vz, rho} by pencil
+// (deposit.hip), so one workgroup accumulates rho and one rho*v component of its pencil in
+// LDS (float atomics), forms v = rho v / rho (or p = rho v Lcell^3) as it loads the FFT's
+// stage-0 inputs from LDS, transforms and writes B[x][kz][y] -- the real-space grid is never
+// written to or read from HBM.  The FFT's exchange buffers alias the rho*v accumulator.
+// ------------------------------------------------------------------------------
+struct PencilParams {
+  const unsigned* records;   // (1 + 4) 32-bit words per particle, sorted by pencil
+  const unsigned* start;     // [npencils + 1]
+  int N, nx, nby;            // grid, slab rows, pencils per x row (N / TP)
+  int ncomp;
+  int chan[3];               // record channel (0..2) feeding component c
+  int divide;                // 1: v = q / rho (0 where rho == 0);  0: p = q * vol
+  float vol;
+  cf* out[3];                // B_c[x][kz][y]
+  cf* nyq[3];                // BN_c[x][y]
+  const cf* tw_stage;
+  const cf* tw_r2c;
+};
+
+template <int NC, int TP>
+__global__ void __launch_bounds__(TP* PlanInfo<NC>::L) pencil_fft_z_kernel(const PencilParams p) {
+  typedef PlanInfo<NC> PI;
+  constexpr int L = PI::L, RL = PI::RL, NT = TP * L, N = 2 * NC;
+  constexpr int ACC = TP * N;                       // floats per accumulator
+  constexpr int LINES = TP * PI::PITCH * 2;         // floats of the exchange buffers
+  constexpr int SHARED = (ACC > LINES ? ACC : LINES);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* acc_rho = reinterpret_cast<float*>(smem_raw);
+  float* acc_q = acc_rho + ACC;                     // aliased by the FFT buffers
+  cf* buf = reinterpret_cast<cf*>(acc_q);
+  cf* tw_lds = reinterpret_cast<cf*>(acc_q + SHARED);
+  const cf* tw = PI::TWLDS ? tw_lds : p.tw_stage;
+
+  const int tid = threadIdx.x;
+  const int t = tid / L, l = tid % L;
+  const unsigned pencil = blockIdx.x;
+  const int x = pencil / p.nby, y0 = (pencil % p.nby) * TP;
+  const unsigned s = p.start[pencil], e = p.start[pencil + 1];
+  if constexpr (PI::TWLDS)
+    for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
+  // The first KR*NT records of the bucket are fetched ONCE into registers (the loads fly while
+  // the accumulators are zeroed); only unusually full pencils touch the records again.
+  constexpr int KR = 4;
+  unsigned rloc[KR];
+  float rq[KR][3], rrho[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const unsigned j = s + tid + k * NT;
+    rloc[k] = 0xffffffffu;
+    if (j < e) {
+      const unsigned* rec = p.records + (size_t)j * 5;
+      rloc[k] = rec[0];
+      rq[k][0] = __uint_as_float(rec[1]);
+      rq[k][1] = __uint_as_float(rec[2]);
+      rq[k][2] = __uint_as_float(rec[3]);
+      rrho[k] = __uint_as_float(rec[4]);
+    }
+  }
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc_rho)[i] = zero4;
+
+  for (int c = 0; c < p.ncomp; ++c) {
+    if (c > 0) __syncthreads();   // previous component's transposed image fully stored
+    for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc_q)[i] = zero4;
+    __syncthreads();
+    const int chn = p.chan[c];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      if (rloc[k] != 0xffffffffu) {
+        const float qv = chn == 0 ? rq[k][0] : (chn == 1 ? rq[k][1] : rq[k][2]);
+        atomicAdd(&acc_q[rloc[k]], qv);
+        if (c == 0) atomicAdd(&acc_rho[rloc[k]], rrho[k]);
+      }
+    }
+    for (unsigned j = s + tid + KR * NT; j < e; j += NT) {
+      const unsigned* rec = p.records + (size_t)j * 5;
+      const unsigned loc = rec[0];
+      atomicAdd(&acc_q[loc], __uint_as_float(rec[1 + chn]));
+      if (c == 0) atomicAdd(&acc_rho[loc], __uint_as_float(rec[4]));
+    }
+    __syncthreads();
+    // stage-0 inputs straight from the accumulators: z[j] = f[2j] + i f[2j+1]
+    cf v[RL];
+    {
+      constexpr int R = PI::R0, NB = RL / R;
+      const float* q = acc_q + t * N;
+      const float* r = acc_rho + t * N;
+#pragma unroll
+      for (int m = 0; m < NB; ++m)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+          const int j = l + L * m + rr * (NC / R);
+          const float2 qq = *reinterpret_cast<const float2*>(q + 2 * j);
+          if (p.divide) {
+            const float2 dd = *reinterpret_cast<const float2*>(r + 2 * j);
+            // one reciprocal per cell; empty cells give 0 (the NaN->0 rule of interp.py:329-331)
+            v[m * R + rr] = make_float2(dd.x != 0.f ? qq.x * __builtin_amdgcn_rcpf(dd.x) : 0.f,
+                                        dd.y != 0.f ? qq.y * __builtin_amdgcn_rcpf(dd.y) : 0.f);
+          } else {
+            v[m * R + rr] = make_float2(qq.x * p.vol, qq.y * p.vol);
+          }
+        }
+    }
+    __syncthreads();   // accumulator of this component consumed: its memory becomes FFT scratch
+    constexpr bool WSYNC = (L <= 64) && (64 % L == 0);
+    fft_from_regs<NC, WSYNC>(v, buf + t * PI::PITCH, tw, l);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RL; ++i) buf[tridx<TP>(out_index<NC>(l, i), t)] = v[i];
+    __syncthreads();
+    cf* out = p.out[c] + (long long)x * NC * N + y0;
+    cf* nyq = p.nyq[c] + (long long)x * N + y0;
+#pragma unroll 4
+    for (int i = 0; i < RL; ++i) {
+      const int idx = tid + i * NT;
+      const int tt = idx % TP, k = idx / TP;
+      const cf zk = buf[tridx<TP>(k, tt)];
+      cf res;
+      if (k == 0) {
+        res = make_float2(zk.x + zk.y, 0.f);
+        nyq[tt] = make_float2(zk.x - zk.y, 0.f);
+      } else {
+        const cf zn = buf[tridx<TP>(NC - k, tt)];
+        const cf w = p.tw_r2c[k];
+        const cf sm = make_float2(zk.x + zn.x, zk.y - zn.y);   // Z[k] + conj(Z[NC-k])
+        const cf d = make_float2(zk.x - zn.x, zk.y + zn.y);    // Z[k] - conj(Z[NC-k])
+        const cf wd = cmul(w, d);
+        res = make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));
+      }
+      out[(long long)k * N + tt] = res;
+    }
+  }
+}
+
+constexpr int PENCIL_TP = 16;
+
+template <int NC>
+size_t pencil_lds_bytes() {
+  typedef PlanInfo<NC> PI;
+  constexpr int ACC = PENCIL_TP * 2 * NC, LINES = PENCIL_TP * PI::PITCH * 2;
+  return (size_t)(ACC + (ACC > LINES ? ACC : LINES)) * sizeof(float) + (size_t)PI::TWL * sizeof(cf);
+}
+
+template <int NC>
+int launch_pencil(vps_ctx* ctx, const PencilParams& p, long long npencils) {
+  typedef PlanInfo<NC> PI;
+  const size_t lds = pencil_lds_bytes<NC>();
+  if (lds > ctx->lds_per_cu) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "pencil kernel needs %zu B LDS", lds);
+  auto kern = pencil_fft_z_kernel<NC, PENCIL_TP>;
+  if (lds > 64 * 1024)
+    VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  {
+    vps_launch_timer tm(ctx, VPS_K_FFT_Z);
+    hipLaunchKernelGGL(kern, dim3((unsigned)npencils), dim3(PENCIL_TP * PI::L), lds, ctx->stream, p);
+  }
+  VPS_HIP_CHECK(ctx, hipGetLastError());
+  return VPS_OK;
 }
 
 // ------------------------------------------------------------------------------
@@ -939,6 +1105,102 @@ int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev, void* spec_d
   VPS_DISPATCH_NC(N, (rc = launch_transpose<NC_, false>(ctx, pn, VPS_K_FFT_Y)));
   return rc;
 }
+
+}  // extern "C"
+
+// y pass of one field: B[x][kz][y] (+BN[x][y]) -> spec[kz][ky][x] (+nyq[ky][x])
+static int fft_y_of(vps_ctx* ctx, int N, int nx, const cf* B, const cf* BN, void* spec_dev, void* nyq_dev) {
+  const int NH = N / 2;
+  vps_fft_tables ty;
+  int rc = vps_fft_get_tables(ctx, N, &ty);
+  if (rc) return rc;
+  PassParams py{};
+  py.in = B;
+  py.out = spec_dev;
+  py.in_sa = (long long)NH * N;
+  py.in_sb = N;
+  py.out_ob = (long long)N * nx;
+  py.out_ok = nx;
+  py.A = nx;
+  py.B = NH;
+  py.tw_stage = ty.tw_stage;
+  VPS_DISPATCH_NC(N, (rc = launch_transpose<NC_, false>(ctx, py, VPS_K_FFT_Y)));
+  if (rc) return rc;
+  PassParams pn = py;
+  pn.in = BN;
+  pn.out = nyq_dev;
+  pn.in_sa = N;
+  pn.in_sb = 0;
+  pn.out_ob = 0;
+  pn.B = 1;
+  VPS_DISPATCH_NC(N, (rc = launch_transpose<NC_, false>(ctx, pn, VPS_K_FFT_Y)));
+  return rc;
+}
+
+int vps_pencil_tp(void) { return PENCIL_TP; }
+
+bool vps_pencil_supported(vps_ctx* ctx, int N) {
+  if (!vps_fft_supported(N) || N < 64 || N > 1024) return false;
+  size_t lds = 0;
+  int rc = VPS_OK;
+  (void)rc;
+  switch (N / 2) {
+    case 32: lds = pencil_lds_bytes<32>(); break;
+    case 64: lds = pencil_lds_bytes<64>(); break;
+    case 128: lds = pencil_lds_bytes<128>(); break;
+    case 256: lds = pencil_lds_bytes<256>(); break;
+    case 512: lds = pencil_lds_bytes<512>(); break;
+    default: return false;
+  }
+  return lds <= ctx->lds_per_cu;
+}
+
+// records sorted by pencil -> ncomp half spectra after the z and y passes
+int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, const unsigned* start,
+                      int ncomp, const int* chan, int divide, float vol, void* spec_dev, void* nyq_dev,
+                      void* bwork_dev) {
+  const int NH = N / 2;
+  vps_fft_tables tz;
+  int rc = vps_fft_get_tables(ctx, NH, &tz);
+  if (rc) return rc;
+  const size_t bfield = (size_t)nx * NH * N, bnyq = (size_t)nx * N;
+  cf* Bbase = reinterpret_cast<cf*>(bwork_dev);
+  PencilParams p{};
+  p.records = records;
+  p.start = start;
+  p.N = N;
+  p.nx = nx;
+  p.nby = N / PENCIL_TP;
+  p.ncomp = ncomp;
+  for (int c = 0; c < 3; ++c) {
+    p.chan[c] = chan[c < ncomp ? c : 0];
+    p.out[c] = Bbase + (size_t)c * (bfield + bnyq);
+    p.nyq[c] = p.out[c] + bfield;
+  }
+  p.divide = divide;
+  p.vol = vol;
+  p.tw_stage = tz.tw_stage;
+  p.tw_r2c = tz.tw_r2c;
+  const long long npencils = (long long)nx * p.nby;
+  switch (NH) {
+    case 32: rc = launch_pencil<32>(ctx, p, npencils); break;
+    case 64: rc = launch_pencil<64>(ctx, p, npencils); break;
+    case 128: rc = launch_pencil<128>(ctx, p, npencils); break;
+    case 256: rc = launch_pencil<256>(ctx, p, npencils); break;
+    case 512: rc = launch_pencil<512>(ctx, p, npencils); break;
+    default: rc = vps_fail(ctx, VPS_ERR_UNSUPPORTED, "pencil path: N=%d", N);
+  }
+  if (rc) return rc;
+  cf* spec = reinterpret_cast<cf*>(spec_dev);
+  cf* nyq = reinterpret_cast<cf*>(nyq_dev);
+  for (int c = 0; c < ncomp; ++c) {
+    rc = fft_y_of(ctx, N, nx, p.out[c], p.nyq[c], spec + (size_t)c * NH * N * nx, nyq + (size_t)c * N * nx);
+    if (rc) return rc;
+  }
+  return VPS_OK;
+}
+
+extern "C" {
 
 int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const void* in_dev,
               int nseg, int64_t seg_stride, int mode, double* psum_dev,

@@ -254,6 +254,24 @@ class HipKernels:
                                              self._ptr(out, torch.float32), self._ptr(work)))
         return out
 
+    def fused_supported(self, N, quantity):
+        return bool(self.lib.vps_deposit_fft_zy_supported(self.ctx, int(N), int(quantity)))
+
+    def deposit_fft_zy(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, spec=None, nyq=None):
+        """Fused deposit + field algebra + z/y passes for a vector quantity:
+        -> spec [3, N/2, N, nx], nyq [3, N, nx] (complex64)."""
+        self._stream()
+        if spec is None:
+            spec = self.empty((3, N // 2, N, nx), torch.complex64)
+        if nyq is None:
+            nyq = self.empty((3, N, nx), torch.complex64)
+        work = self.workspace("fused", self.lib.vps_deposit_fft_zy_workspace_bytes(pos.shape[0], N, nx))
+        self._chk(self.lib.vps_deposit_fft_zy(self.ctx, self._ptr(pos), self._pos_kind(pos),
+                                              self._ptr(vel, torch.float32), self._ptr(rho, torch.float32),
+                                              pos.shape[0], N, float(Lbox), x0, nx, quantity, flags,
+                                              self._ptr(spec), self._ptr(nyq), self._ptr(work)))
+        return spec, nyq
+
     def nn_resample(self, pos, payload, axes, x0, nx, want_index=False, out=None):
         """Exact NN of every lattice point axes[0][x0:x0+nx] x axes[1] x axes[2]."""
         self._stream()
@@ -473,6 +491,24 @@ class PowerPipeline:
             nyq = self.comm.all_to_all(nyq)
             k.fft_x_bin(spec, N, nkz * N, 0, r * nkz, G, nkz * N * nx, psum, nsample, count=c)
             k.fft_x_bin(nyq, N, nky, r * nky, N // 2, G, nky * nx, psum, nsample, count=c)
+        return psum, nsample
+
+    def accumulate_spectra(self, spec, nyq, psum=None, nsample=None, count=True):
+        """Like `accumulate`, for fields that already went through the z and y passes
+        (spec [ncomp, N/2, N, nx], nyq [ncomp, N, nx], e.g. from HipKernels.deposit_fft_zy)."""
+        N, nx, G, r = self.N, self.nx, self.comm.world, self.comm.rank
+        k = self.k
+        k.set_binning(*self._binning)
+        if psum is None:
+            psum = k.zeros((self.nbins,), torch.float64)
+            nsample = k.zeros((self.nbins,), torch.int64)
+        nkz, nky = N // 2 // G, N // G
+        for i in range(spec.shape[0]):
+            c = count and i == 0
+            s = self.comm.all_to_all(spec[i])
+            q = self.comm.all_to_all(nyq[i])
+            k.fft_x_bin(s, N, nkz * N, 0, r * nkz, G, nkz * N * nx, psum, nsample, count=c)
+            k.fft_x_bin(q, N, nky, r * nky, N // 2, G, nky * nx, psum, nsample, count=c)
         return psum, nsample
 
     def finish(self, psum, nsample):

@@ -356,6 +356,43 @@ def test_config1_full_size_against_oracle():
     assert np.allclose(tab[:, 1], ref[:, 1], rtol=PSUM_RTOL, atol=0)
 
 
+# ------------------------------------------------ fused deposit -> z pass (pencils) ----
+@pytest.mark.parametrize("N,nx,x0", [(64, 64, 0), (128, 128, 0), (128, 32, 64), (256, 256, 0), (512, 64, 448)])
+@pytest.mark.parametrize("quantity,flags", [("velocity", 0), ("momentum", 0), ("momentum", 1)])
+def test_fused_deposit_fft_matches_unfused(K, N, nx, x0, quantity, flags):
+    from vpower import device
+    q = device.QUANTITY[quantity]
+    assert K.fused_supported(N, q) and not K.fused_supported(N, device.ENERGY) and not K.fused_supported(2048, q)
+    rng = np.random.default_rng(N + nx)
+    Np = 150000
+    pos = rng.random((Np, 3)).astype(np.float32)
+    pos[: Np // 5] = pos[: Np // 5] * 0.1 + 0.45            # a clump: some very full pencils
+    dpos = K.to_device(pos)
+    dvel = K.to_device(rng.standard_normal((Np, 3)).astype(np.float32))
+    drho = K.to_device(np.exp(rng.standard_normal(Np)).astype(np.float32))
+    fields = K.deposit_field(dpos, dvel, drho, N, 1.0, x0, nx, q, flags)
+    spec, nyq = K.deposit_fft_zy(dpos, dvel, drho, N, 1.0, x0, nx, q, flags)
+    for c in range(3):
+        s_ref, n_ref = K.fft_zy(fields[c], N, nx)
+        scale = float(s_ref.abs().pow(2).mean().sqrt())
+        assert float((spec[c] - s_ref).abs().max()) / scale < 2e-5
+        assert float((nyq[c] - n_ref).abs().max()) / scale < 2e-5
+
+
+def test_fused_pipeline_against_oracle(K):
+    from vpower import device
+    N, L, Np = 64, 1.0, 60000
+    pos, vel, mass, dens = synth(77, Np, L)
+    spec, nyq = K.deposit_fft_zy(K.to_device(pos), K.to_device(vel), K.to_device(dens), N, L, 0, N, device.VELOCITY)
+    pipe = device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False))
+    tab = pipe.finish(*pipe.accumulate_spectra(spec, nyq))
+    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
+    v, m = orc.vm_from_vec_grid(orc.deposit_to_grid(vec, pos, N, L), L / N, zero_empty=True)
+    ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, L / N, "velocity")
+    assert np.array_equal(tab[:, 3], ref[:, 3])
+    assert np.allclose(tab[:, 2], ref[:, 2], rtol=PSUM_RTOL, atol=0)
+
+
 # ------------------------------------------------------------------- edge cases ----
 def test_edge_cases_empty_single_and_errors(K):
     from vpower import device, interp, _ffi
