@@ -99,8 +99,6 @@ def main():
     dpos, dvel, drho = K.to_device(pos), K.to_device(vel), K.to_device(dens)
     del pos, vel, mass, dens
     grid = K.empty((3, nx, N, N), torch.float32)
-    spec = K.empty((N // 2, N, nx), torch.complex64)
-    nyq = K.empty((N, nx), torch.complex64)
     psum = K.zeros((pipe.nbins,), torch.float64)
     nsample = K.zeros((pipe.nbins,), torch.int64)
     G = world
@@ -114,21 +112,15 @@ def main():
     def step():
         psum.zero_()
         nsample.zero_()
-        K.set_binning(*pipe._binning)
         if fused:
             # deposit + v = rho v / rho + z pass in one kernel (pencil buckets), then the y passes
             K.deposit_fft_zy(dpos, dvel, drho, N, L, x0, nx, device.VELOCITY, spec=spec3, nyq=nyq3)
         else:
             K.deposit_field(dpos, dvel, drho, N, L, x0, nx, device.VELOCITY, out=grid)
-        for c in range(3):
-            if fused:
-                s, q = spec3[c], nyq3[c]
-            else:
-                s, q = K.fft_zy(grid[c], N, nx, spec=spec, nyq=nyq)
-            s = comm.all_to_all(s)
-            q = comm.all_to_all(q)
-            K.fft_x_bin(s, N, nkz * N, 0, rank * nkz, G, nkz * N * nx, psum, nsample, count=(c == 0))
-            K.fft_x_bin(q, N, nky, rank * nky, N // 2, G, nky * nx, psum, nsample, count=(c == 0))
+        if fused:
+            pipe.accumulate_spectra(spec3, nyq3, psum, nsample)     # 3 x (all-to-all, x pass + binning)
+        else:
+            pipe.accumulate([grid[0], grid[1], grid[2]], psum, nsample)   # 3 x (z/y passes, all-to-all, x pass)
         tab = pipe.finish(psum, nsample)     # all-reduce, D2H, table
         tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2
         return tab

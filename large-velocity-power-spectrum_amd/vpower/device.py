@@ -404,27 +404,43 @@ class SlabComm:
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.backend = dist.get_backend(group) if self.enabled else None
 
-    def all_to_all(self, send):
-        """Equal-split all-to-all along dim 0 of a contiguous tensor."""
+    def all_to_all_start(self, send):
+        """Begin an equal-split all-to-all along dim 0 of a contiguous tensor.  Returns
+        (recv, work); `all_to_all_finish` makes `recv` usable on the current stream.  With
+        RCCL the exchange runs on the communicator's stream, so kernels issued in between
+        (the z/y passes of the next field, the x pass of the previous one) overlap it."""
         if self.world == 1:
-            return send
+            return send, None
         if send.is_cuda and self.backend != "nccl":
-            # gloo rehearsal on a GPU box: stage through host memory
+            # gloo rehearsal on a GPU box: stage through host memory (synchronous)
             h = send.cpu()
             r = torch.empty_like(h)
             self.dist.all_to_all_single(r, h, group=self.group)
-            return r.to(send.device)
-        if send.is_complex() and self.backend != "nccl":
-            s = torch.view_as_real(send).contiguous()
-            r = torch.empty_like(s)
-            self.dist.all_to_all_single(r, s, group=self.group)
-            return torch.view_as_complex(r)
-        recv = torch.empty_like(send)
+            return r.to(send.device), None
         if send.is_complex():
-            self.dist.all_to_all_single(torch.view_as_real(recv), torch.view_as_real(send), group=self.group)
-        else:
-            self.dist.all_to_all_single(recv, send, group=self.group)
+            s = torch.view_as_real(send)
+            recv = torch.empty_like(send)
+            r = torch.view_as_real(recv)
+            if not send.is_cuda:           # gloo wants plain contiguous real tensors
+                s = s.contiguous()
+                r = torch.empty_like(s)
+                recv = torch.view_as_complex(r)
+            work = self.dist.all_to_all_single(r, s, group=self.group, async_op=True)
+            return recv, (work, s)        # keep the send view alive until the wait
+        recv = torch.empty_like(send)
+        work = self.dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+        return recv, (work, send)
+
+    @staticmethod
+    def all_to_all_finish(handle):
+        recv, work = handle
+        if work is not None:
+            work[0].wait()
         return recv
+
+    def all_to_all(self, send):
+        """Blocking form of all_to_all_start / all_to_all_finish."""
+        return self.all_to_all_finish(self.all_to_all_start(send))
 
     def all_reduce_sum(self, t):
         if self.world == 1:
@@ -484,11 +500,16 @@ class PowerPipeline:
             nsample = k.zeros((self.nbins,), torch.int64)
         nkz = N // 2 // G      # kz rows per rank after the exchange
         nky = N // G           # Nyquist-plane ky rows per rank
-        for i, f in enumerate(fields):
-            c = count and i == 0
+        # issue every field's z/y passes and start its exchange right away, then run the x
+        # passes as the exchanges complete: communication overlaps the neighbouring fields' compute
+        pending = []
+        for f in fields:
             spec, nyq = k.fft_zy(f, N, nx)
-            spec = self.comm.all_to_all(spec)
-            nyq = self.comm.all_to_all(nyq)
+            pending.append((self.comm.all_to_all_start(spec), self.comm.all_to_all_start(nyq)))
+        for i, (hs, hq) in enumerate(pending):
+            c = count and i == 0
+            spec = self.comm.all_to_all_finish(hs)
+            nyq = self.comm.all_to_all_finish(hq)
             k.fft_x_bin(spec, N, nkz * N, 0, r * nkz, G, nkz * N * nx, psum, nsample, count=c)
             k.fft_x_bin(nyq, N, nky, r * nky, N // 2, G, nky * nx, psum, nsample, count=c)
         return psum, nsample
@@ -503,10 +524,12 @@ class PowerPipeline:
             psum = k.zeros((self.nbins,), torch.float64)
             nsample = k.zeros((self.nbins,), torch.int64)
         nkz, nky = N // 2 // G, N // G
-        for i in range(spec.shape[0]):
+        pending = [(self.comm.all_to_all_start(spec[i]), self.comm.all_to_all_start(nyq[i]))
+                   for i in range(spec.shape[0])]
+        for i, (hs, hq) in enumerate(pending):
             c = count and i == 0
-            s = self.comm.all_to_all(spec[i])
-            q = self.comm.all_to_all(nyq[i])
+            s = self.comm.all_to_all_finish(hs)
+            q = self.comm.all_to_all_finish(hq)
             k.fft_x_bin(s, N, nkz * N, 0, r * nkz, G, nkz * N * nx, psum, nsample, count=c)
             k.fft_x_bin(q, N, nky, r * nky, N // 2, G, nky * nx, psum, nsample, count=c)
         return psum, nsample
