@@ -396,10 +396,11 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
 // Fused deposit + field algebra + z pass ("pencil" kernel).  A pencil is the TP z-lines
 // (x, y0..y0+TP-1, all z) that one z-pass tile transforms.  The deposit stage has sorted
 // the particle records {cell-in-pencil, rho vx, rho vy, rho vz, rho} by pencil
-// (deposit.hip), so one workgroup accumulates rho and one rho*v component of its pencil in
-// LDS (float atomics), forms v = rho v / rho (or p = rho v Lcell^3) as it loads the FFT's
-// stage-0 inputs from LDS, transforms and writes B[x][kz][y] -- the real-space grid is never
-// written to or read from HBM.  The FFT's exchange buffers alias the rho*v accumulator.
+// (deposit.hip), so one workgroup accumulates rho of its pencil in LDS (float atomics), keeps
+// 1/rho of its own stage-0 cells in registers, then per component accumulates rho*v in the same
+// LDS region, forms v = rho v / rho (or p = rho v Lcell^3) as it loads the FFT's stage-0 inputs,
+// transforms and writes B[x][kz][y] -- the real-space grid is never written to or read from
+// HBM, and the accumulator, exchange buffers and transposed image all share one LDS region.
 // ------------------------------------------------------------------------------
 struct PencilParams {
   const unsigned* records;   // (1 + 4) 32-bit words per particle, sorted by pencil
@@ -415,18 +416,28 @@ struct PencilParams {
   const cf* tw_r2c;
 };
 
+// tuning knobs (measured at 512^3 / 1024^3): 4 waves/SIMD needs <= 128 VGPRs; 2 preloaded record groups
+#ifndef VPS_PENCIL_MINW
+#define VPS_PENCIL_MINW 4
+#endif
+#ifndef VPS_PENCIL_KR
+#define VPS_PENCIL_KR 2
+#endif
+
 template <int NC, int TP>
-__global__ void __launch_bounds__(TP* PlanInfo<NC>::L) pencil_fft_z_kernel(const PencilParams p) {
+__global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_fft_z_kernel(const PencilParams p) {
   typedef PlanInfo<NC> PI;
   constexpr int L = PI::L, RL = PI::RL, NT = TP * L, N = 2 * NC;
-  constexpr int ACC = TP * N;                       // floats per accumulator
+  constexpr int ACC = TP * N;                       // floats of one accumulator
   constexpr int LINES = TP * PI::PITCH * 2;         // floats of the exchange buffers
   constexpr int SHARED = (ACC > LINES ? ACC : LINES);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* acc_rho = reinterpret_cast<float*>(smem_raw);
-  float* acc_q = acc_rho + ACC;                     // aliased by the FFT buffers
-  cf* buf = reinterpret_cast<cf*>(acc_q);
-  cf* tw_lds = reinterpret_cast<cf*>(acc_q + SHARED);
+  // ONE LDS region serves, in turn, as the rho accumulator, each rho*v accumulator and the FFT's
+  // exchange / transposed-image buffer; 1/rho of the cells a thread feeds into stage 0 lives in
+  // its registers (the cells are the same for every component).
+  float* acc = reinterpret_cast<float*>(smem_raw);
+  cf* buf = reinterpret_cast<cf*>(acc);
+  cf* tw_lds = reinterpret_cast<cf*>(acc + SHARED);
   const cf* tw = PI::TWLDS ? tw_lds : p.tw_stage;
 
   const int tid = threadIdx.x;
@@ -437,8 +448,8 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L) pencil_fft_z_kernel(const
   if constexpr (PI::TWLDS)
     for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
   // The first KR*NT records of the bucket are fetched ONCE into registers (the loads fly while
-  // the accumulators are zeroed); only unusually full pencils touch the records again.
-  constexpr int KR = 4;
+  // the accumulator is zeroed); only unusually full pencils touch the records again.
+  constexpr int KR = VPS_PENCIL_KR;
   unsigned rloc[KR];
   float rq[KR][3], rrho[KR];
 #pragma unroll
@@ -455,62 +466,82 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L) pencil_fft_z_kernel(const
     }
   }
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc_rho)[i] = zero4;
+  constexpr int R0 = PI::R0, NB0 = RL / R0;
+  float2 scale[RL];   // per stage-0 input cell pair: 1/rho (0 where empty) or Lcell^3
+  if (p.divide) {
+    for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+      if (rloc[k] != 0xffffffffu) atomicAdd(&acc[rloc[k]], rrho[k]);
+    for (unsigned j = s + tid + KR * NT; j < e; j += NT) {
+      const unsigned* rec = p.records + (size_t)j * 5;
+      atomicAdd(&acc[rec[0]], __uint_as_float(rec[4]));
+    }
+    __syncthreads();
+    const float* r = acc + t * N;
+#pragma unroll
+    for (int m = 0; m < NB0; ++m)
+#pragma unroll
+      for (int rr = 0; rr < R0; ++rr) {
+        const int j = l + L * m + rr * (NC / R0);
+        const float2 dd = *reinterpret_cast<const float2*>(r + 2 * j);
+        // one reciprocal per cell; empty cells give 0 (the NaN->0 rule of interp.py:329-331)
+        scale[m * R0 + rr] = make_float2(dd.x != 0.f ? __builtin_amdgcn_rcpf(dd.x) : 0.f,
+                                         dd.y != 0.f ? __builtin_amdgcn_rcpf(dd.y) : 0.f);
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < RL; ++i) scale[i] = make_float2(p.vol, p.vol);
+  }
 
   for (int c = 0; c < p.ncomp; ++c) {
-    if (c > 0) __syncthreads();   // previous component's transposed image fully stored
-    for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc_q)[i] = zero4;
+    // opaque copies: keeps the compiler from hoisting ~50 loop-invariant LDS addresses out of the
+    // component loop (they cost more registers than the 1/rho table and an occupancy step)
+    int lc = l, tc = t, tidc = tid;
+    asm volatile("" : "+v"(lc), "+v"(tc), "+v"(tidc));
+    __syncthreads();   // rho / previous component's transposed image fully consumed
+    for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
     __syncthreads();
     const int chn = p.chan[c];
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
       if (rloc[k] != 0xffffffffu) {
         const float qv = chn == 0 ? rq[k][0] : (chn == 1 ? rq[k][1] : rq[k][2]);
-        atomicAdd(&acc_q[rloc[k]], qv);
-        if (c == 0) atomicAdd(&acc_rho[rloc[k]], rrho[k]);
+        atomicAdd(&acc[rloc[k]], qv);
       }
     }
     for (unsigned j = s + tid + KR * NT; j < e; j += NT) {
       const unsigned* rec = p.records + (size_t)j * 5;
-      const unsigned loc = rec[0];
-      atomicAdd(&acc_q[loc], __uint_as_float(rec[1 + chn]));
-      if (c == 0) atomicAdd(&acc_rho[loc], __uint_as_float(rec[4]));
+      atomicAdd(&acc[rec[0]], __uint_as_float(rec[1 + chn]));
     }
     __syncthreads();
-    // stage-0 inputs straight from the accumulators: z[j] = f[2j] + i f[2j+1]
+    // stage-0 inputs straight from the accumulator: z[j] = f[2j] + i f[2j+1]
     cf v[RL];
     {
-      constexpr int R = PI::R0, NB = RL / R;
-      const float* q = acc_q + t * N;
-      const float* r = acc_rho + t * N;
+      const float* q = acc + tc * N;
 #pragma unroll
-      for (int m = 0; m < NB; ++m)
+      for (int m = 0; m < NB0; ++m)
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-          const int j = l + L * m + rr * (NC / R);
+        for (int rr = 0; rr < R0; ++rr) {
+          const int j = lc + L * m + rr * (NC / R0);
           const float2 qq = *reinterpret_cast<const float2*>(q + 2 * j);
-          if (p.divide) {
-            const float2 dd = *reinterpret_cast<const float2*>(r + 2 * j);
-            // one reciprocal per cell; empty cells give 0 (the NaN->0 rule of interp.py:329-331)
-            v[m * R + rr] = make_float2(dd.x != 0.f ? qq.x * __builtin_amdgcn_rcpf(dd.x) : 0.f,
-                                        dd.y != 0.f ? qq.y * __builtin_amdgcn_rcpf(dd.y) : 0.f);
-          } else {
-            v[m * R + rr] = make_float2(qq.x * p.vol, qq.y * p.vol);
-          }
+          const float2 sc = scale[m * R0 + rr];
+          v[m * R0 + rr] = make_float2(qq.x * sc.x, qq.y * sc.y);
         }
     }
     __syncthreads();   // accumulator of this component consumed: its memory becomes FFT scratch
     constexpr bool WSYNC = (L <= 64) && (64 % L == 0);
-    fft_from_regs<NC, WSYNC>(v, buf + t * PI::PITCH, tw, l);
+    fft_from_regs<NC, WSYNC>(v, buf + tc * PI::PITCH, tw, lc);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RL; ++i) buf[tridx<TP>(out_index<NC>(l, i), t)] = v[i];
+    for (int i = 0; i < RL; ++i) buf[tridx<TP>(out_index<NC>(lc, i), tc)] = v[i];
     __syncthreads();
     cf* out = p.out[c] + (long long)x * NC * N + y0;
     cf* nyq = p.nyq[c] + (long long)x * N + y0;
 #pragma unroll 4
     for (int i = 0; i < RL; ++i) {
-      const int idx = tid + i * NT;
+      const int idx = tidc + i * NT;
       const int tt = idx % TP, k = idx / TP;
       const cf zk = buf[tridx<TP>(k, tt)];
       cf res;
@@ -536,7 +567,7 @@ template <int NC>
 size_t pencil_lds_bytes() {
   typedef PlanInfo<NC> PI;
   constexpr int ACC = PENCIL_TP * 2 * NC, LINES = PENCIL_TP * PI::PITCH * 2;
-  return (size_t)(ACC + (ACC > LINES ? ACC : LINES)) * sizeof(float) + (size_t)PI::TWL * sizeof(cf);
+  return (size_t)(ACC > LINES ? ACC : LINES) * sizeof(float) + (size_t)PI::TWL * sizeof(cf);
 }
 
 template <int NC>
@@ -1140,7 +1171,7 @@ static int fft_y_of(vps_ctx* ctx, int N, int nx, const cf* B, const cf* BN, void
 int vps_pencil_tp(void) { return PENCIL_TP; }
 
 bool vps_pencil_supported(vps_ctx* ctx, int N) {
-  if (!vps_fft_supported(N) || N < 64 || N > 1024) return false;
+  if (!vps_fft_supported(N) || N < 64 || N > 2048) return false;
   size_t lds = 0;
   int rc = VPS_OK;
   (void)rc;
@@ -1150,6 +1181,7 @@ bool vps_pencil_supported(vps_ctx* ctx, int N) {
     case 128: lds = pencil_lds_bytes<128>(); break;
     case 256: lds = pencil_lds_bytes<256>(); break;
     case 512: lds = pencil_lds_bytes<512>(); break;
+    case 1024: lds = pencil_lds_bytes<1024>(); break;
     default: return false;
   }
   return lds <= ctx->lds_per_cu;
@@ -1188,6 +1220,7 @@ int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, cons
     case 128: rc = launch_pencil<128>(ctx, p, npencils); break;
     case 256: rc = launch_pencil<256>(ctx, p, npencils); break;
     case 512: rc = launch_pencil<512>(ctx, p, npencils); break;
+    case 1024: rc = launch_pencil<1024>(ctx, p, npencils); break;
     default: rc = vps_fail(ctx, VPS_ERR_UNSUPPORTED, "pencil path: N=%d", N);
   }
   if (rc) return rc;

@@ -357,12 +357,13 @@ def test_config1_full_size_against_oracle():
 
 
 # ------------------------------------------------ fused deposit -> z pass (pencils) ----
-@pytest.mark.parametrize("N,nx,x0", [(64, 64, 0), (128, 128, 0), (128, 32, 64), (256, 256, 0), (512, 64, 448)])
+@pytest.mark.parametrize("N,nx,x0", [(64, 64, 0), (128, 128, 0), (128, 32, 64), (256, 256, 0), (512, 64, 448), (1024, 16, 480),
+                                     (2048, 4, 1000)])
 @pytest.mark.parametrize("quantity,flags", [("velocity", 0), ("momentum", 0), ("momentum", 1)])
 def test_fused_deposit_fft_matches_unfused(K, N, nx, x0, quantity, flags):
     from vpower import device
     q = device.QUANTITY[quantity]
-    assert K.fused_supported(N, q) and not K.fused_supported(N, device.ENERGY) and not K.fused_supported(2048, q)
+    assert K.fused_supported(N, q) and not K.fused_supported(N, device.ENERGY) and not K.fused_supported(4096, q)
     rng = np.random.default_rng(N + nx)
     Np = 150000
     pos = rng.random((Np, 3)).astype(np.float32)
