@@ -57,22 +57,45 @@ __device__ __forceinline__ F np_floor_divide(F a, F b) {
   return fd;
 }
 
-// numpy npy_divmod: the modulus part
+// fmod(q, n) for an integer-valued q and a positive integer n, both below 2^mantissa: one division.
+// Exact: a non-integer q/n is at least 1/n away from every integer while its rounding error is below
+// (q/n) 2^-mantissa < 1/n, so trunc() cannot cross one; trunc(q/n) n <= |q| and the remainder are exact.
+// (fmod proper is a long routine, in double a very long one.)
 template <typename F>
-__device__ __forceinline__ F np_remainder(F a, F b) {
-  F mod = dev_fmod<F>(a, b);
-  if (mod != F(0)) {
-    if ((b < F(0)) != (mod < F(0))) mod += b;
-  } else {
-    mod = copysign(F(0), b);
+__device__ __forceinline__ F fmod_integral(F q, F n) {
+  constexpr F lim = sizeof(F) == 4 ? F(16777216.0) : F(9007199254740992.0);
+  if (fabs(q) < lim && n < lim) {
+    const F r = q - trunc(q / n) * n;
+    return copysign(r, q);          // fmod's zero carries the sign of the dividend
   }
-  return mod;
+  return dev_fmod<F>(q, n);
 }
 
 template <typename F>
 __device__ __forceinline__ int cell_of(F x, F lcell, F nsize) {
-  // int((x // Lcell) % N): float -> int cast truncates
-  return (int)np_remainder<F>(np_floor_divide<F>(x, lcell), nsize);
+  // int((x // Lcell) % N): float -> int cast truncates.
+  // Fast path (every in-range input): numpy's floor_divide returns the exact floor of the real quotient
+  // x / Lcell whenever that is far below 2^mantissa ((x - fmod) / Lcell is then an exact integer), and
+  // the correctly rounded q = x / Lcell has the same floor unless q itself is an integer -- where the
+  // sign of the exact residual fma(-q, Lcell, x) says whether the real quotient lies just below it.
+  // The remainder of the integer fd by the integer N is one more division (exact: fd / N is at least
+  // 1/N from any integer it does not equal, its rounding error below that).
+  constexpr F lim = sizeof(F) == 4 ? F(4194304.0) : F(2251799813685248.0);   // 2^22, 2^51
+  const F q = x / lcell;
+  if (fabs(q) < lim && nsize < lim && lcell > F(0) && nsize >= F(1)) {
+    F fd = floor(q);
+    if (fd == q && fma(-q, lcell, x) < F(0)) fd -= F(1);
+    return (int)(fd - floor(fd / nsize) * nsize);
+  }
+  // anything else (huge, inf, NaN): numpy's npy_divmod steps verbatim
+  const F fdn = np_floor_divide<F>(x, lcell);
+  F mod = fmod_integral<F>(fdn, nsize);
+  if (mod != F(0)) {
+    if ((nsize < F(0)) != (mod < F(0))) mod += nsize;
+  } else {
+    mod = copysign(F(0), nsize);
+  }
+  return (int)mod;
 }
 
 template <typename F>
@@ -159,6 +182,197 @@ __global__ void __launch_bounds__(256)
   rec[0] = loc;
 #pragma unroll
   for (int c = 0; c < C; ++c) rec[1 + c] = __float_as_uint(val[c]);
+}
+
+// ------------------------------------------------------------------------------
+// Two-level bucket sort: the same records / start[] as rank -> scan -> scatter above, but
+// without a global atomic per particle (memory-side atomics cap that pass at ~2.4e10
+// particles/s) and without 20-byte random writes.
+//   level 1: chunks of SORT_CHUNK particles; per-chunk LDS histogram over coarse groups of
+//            2^gshift consecutive buckets -> table[group][chunk] -> exclusive scan -> each chunk
+//            ranks its particles in LDS and writes {key, payload} into its own contiguous run
+//            of every group
+//   level 2: one workgroup per group: LDS histogram over the group's buckets, LDS scan
+//            (-> start[]), second sweep places {loc, payload} at its final slot
+// Slots inside one bucket come out in no particular order (as with the atomic ranks).
+// ------------------------------------------------------------------------------
+#ifndef VPS_SORT_THREADS
+#define VPS_SORT_THREADS 1024
+#endif
+#ifndef VPS_SORT_ITEMS
+#define VPS_SORT_ITEMS 16
+#endif
+constexpr int SORT_THREADS = VPS_SORT_THREADS;   // level 1: chunk = SORT_THREADS * SORT_ITEMS particles
+constexpr int SORT_ITEMS = VPS_SORT_ITEMS;
+constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;
+constexpr int FINE_THREADS = 1024;  // level 2: one big workgroup per group
+constexpr unsigned SORT_INVALID = 0xffffffffu;
+// words per level-1 record {key, payload[C]}.  (Padding the 5-word record of C = 4 to an aligned 32-byte sector was
+// measured: the level-1 scatter gains 10 %, level 2 loses 50 % to the extra bytes.)
+__host__ __device__ constexpr int sort_rec1_words(int C) { return C + 1; }
+
+struct SortGeom {
+  int gshift, ngroups;     // buckets per group = 1 << gshift
+  int cshift;              // log2(cells) when cells is a power of two, else -1
+  unsigned cells;
+  long long nbuckets, nchunks;
+};
+
+__device__ __forceinline__ unsigned sort_bucket_of(unsigned key, const SortGeom& g) {
+  return g.cshift >= 0 ? (key >> g.cshift) : (key / g.cells);
+}
+
+template <typename F>
+__global__ void __launch_bounds__(SORT_THREADS)
+    sort_hist_kernel(const F* __restrict__ pos, long long np, F lcell, F nsize, Bricks b, SortGeom g,
+                     unsigned* __restrict__ keys, unsigned* __restrict__ table) {
+  extern __shared__ unsigned sort_lds[];
+  for (int i = threadIdx.x; i < g.ngroups; i += SORT_THREADS) sort_lds[i] = 0;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * SORT_CHUNK;
+#pragma unroll 4
+  for (int k = 0; k < SORT_ITEMS; ++k) {
+    const long long i = base + (long long)k * SORT_THREADS + threadIdx.x;
+    if (i < np) {
+      unsigned brick, loc, key = SORT_INVALID;
+      if (locate<F>(pos, i, lcell, nsize, b, brick, loc)) {
+        key = brick * g.cells + loc;
+        atomicAdd(&sort_lds[brick >> g.gshift], 1u);
+      }
+      keys[i] = key;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < g.ngroups; i += SORT_THREADS)
+    table[(long long)i * g.nchunks + blockIdx.x] = sort_lds[i];
+}
+
+template <int C, bool RHOV>
+__device__ __forceinline__ void load_payload(const float* __restrict__ payload, const float* __restrict__ rho,
+                                             long long i, float val[C]) {
+  if constexpr (RHOV) {
+    static_assert(C == 4, "rho*v payload has four channels");
+    const float r = rho[i];
+    val[0] = payload[i * 3 + 0] * r;
+    val[1] = payload[i * 3 + 1] * r;
+    val[2] = payload[i * 3 + 2] * r;
+    val[3] = r;
+  } else if constexpr (C == 4) {
+    const float4 p4 = *reinterpret_cast<const float4*>(payload + i * 4);
+    val[0] = p4.x; val[1] = p4.y; val[2] = p4.z; val[3] = p4.w;
+  } else {
+#pragma unroll
+    for (int c = 0; c < C; ++c) val[c] = payload[i * C + c];
+  }
+}
+
+template <int C, bool RHOV>
+__global__ void __launch_bounds__(SORT_THREADS)
+    sort_scatter_kernel(const unsigned* __restrict__ keys, const float* __restrict__ payload,
+                        const float* __restrict__ rho, long long np, SortGeom g,
+                        const unsigned* __restrict__ table_start, unsigned* __restrict__ rec1) {
+  extern __shared__ unsigned sort_lds[];
+  for (int i = threadIdx.x; i < g.ngroups; i += SORT_THREADS)
+    sort_lds[i] = table_start[(long long)i * g.nchunks + blockIdx.x];
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * SORT_CHUNK;
+#pragma unroll 4
+  for (int k = 0; k < SORT_ITEMS; ++k) {
+    const long long i = base + (long long)k * SORT_THREADS + threadIdx.x;
+    if (i >= np) continue;
+    const unsigned key = keys[i];
+    if (key == SORT_INVALID) continue;
+    float val[C];
+    load_payload<C, RHOV>(payload, rho, i, val);
+    const unsigned slot = atomicAdd(&sort_lds[sort_bucket_of(key, g) >> g.gshift], 1u);
+    constexpr int W = sort_rec1_words(C);
+    unsigned w[W];
+    w[0] = key;
+#pragma unroll
+    for (int c = 0; c < C; ++c) w[1 + c] = __float_as_uint(val[c]);
+#pragma unroll
+    for (int c = C + 1; c < W; ++c) w[c] = 0;
+    unsigned* rec = rec1 + (size_t)slot * W;
+    if constexpr (W == 2) {
+      *reinterpret_cast<uint2*>(rec) = make_uint2(w[0], w[1]);
+    } else if constexpr (W == 4) {
+      *reinterpret_cast<uint4*>(rec) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < W; ++c) rec[c] = w[c];
+    }
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(FINE_THREADS)
+    sort_fine_kernel(const unsigned* __restrict__ rec1, SortGeom g, const unsigned* __restrict__ table_start,
+                     unsigned* __restrict__ start, unsigned* __restrict__ records) {
+  extern __shared__ unsigned sort_lds[];          // [G] cursors, then [FINE_THREADS] scan scratch
+  const int G = 1 << g.gshift;
+  unsigned* cur = sort_lds;
+  unsigned* part = sort_lds + G;
+  const int grp = blockIdx.x;
+  const unsigned gs = table_start[(long long)grp * g.nchunks];
+  const unsigned ge = table_start[(long long)(grp + 1) * g.nchunks];   // [ngroups*nchunks] = total
+  for (int i = threadIdx.x; i < G; i += FINE_THREADS) cur[i] = 0;
+  __syncthreads();
+  for (unsigned j = gs + threadIdx.x; j < ge; j += FINE_THREADS)
+    atomicAdd(&cur[sort_bucket_of(rec1[(size_t)j * sort_rec1_words(C)], g) & (G - 1)], 1u);
+  __syncthreads();
+  // exclusive scan of cur[0..G): thread t owns `per` consecutive entries
+  const int per = (G + FINE_THREADS - 1) / FINE_THREADS;
+  unsigned mine = 0;
+  for (int k = 0; k < per; ++k) {
+    const int f = threadIdx.x * per + k;
+    if (f < G) mine += cur[f];
+  }
+  part[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 1; off < FINE_THREADS; off <<= 1) {
+    const unsigned add = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  unsigned run = gs + part[threadIdx.x] - mine;
+  for (int k = 0; k < per; ++k) {
+    const int f = threadIdx.x * per + k;
+    if (f < G) {
+      const unsigned cnt = cur[f];
+      cur[f] = run;
+      const long long bucket = (long long)grp * G + f;
+      if (bucket < g.nbuckets) start[bucket] = run;
+      run += cnt;
+    }
+  }
+  if (grp == g.ngroups - 1 && threadIdx.x == 0) start[g.nbuckets] = ge;
+  __syncthreads();
+  for (unsigned j = gs + threadIdx.x; j < ge; j += FINE_THREADS) {
+    constexpr int W = sort_rec1_words(C);
+    const unsigned* src = rec1 + (size_t)j * W;
+    unsigned r[W];
+    if constexpr (W == 2) {
+      const uint2 t = *reinterpret_cast<const uint2*>(src);
+      r[0] = t.x; r[1] = t.y;
+    } else if constexpr (W == 4) {
+      const uint4 t = *reinterpret_cast<const uint4*>(src);
+      r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < W; ++c) r[c] = src[c];
+    }
+    const unsigned key = r[0];
+    unsigned w[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) w[c] = r[1 + c];
+    const unsigned bucket = sort_bucket_of(key, g);
+    const unsigned slot = atomicAdd(&cur[bucket & (G - 1)], 1u);
+    unsigned* dst = records + (size_t)slot * (C + 1);
+    dst[0] = key - bucket * g.cells;
+#pragma unroll
+    for (int c = 0; c < C; ++c) dst[1 + c] = w[c];
+  }
 }
 
 // Epilogue of the brick kernel: what is written for a cell from its C accumulated channels.
@@ -401,13 +615,49 @@ Bricks make_pencils(int N, int x0, int nx, int TP) {
 }
 
 struct DepLayout {
-  size_t count, start, tiles, keys, ranks, records, total;
+  size_t count, start, tiles, keys, ranks, records, table, table_start, table_tiles, rec1, total;
   long long nbricks;
+  bool two_level;
+  SortGeom geom;
 };
+
+// groups per launch the two-level sort aims for (level-2 workgroups); VPS_SORT_GROUPS overrides (tuning)
+int sort_target_groups() {
+  static int v = 0;
+  if (!v) {
+    const char* e = getenv("VPS_SORT_GROUPS");
+    v = e ? atoi(e) : 1024;
+    if (v < 1) v = 1;
+    if (v > 4096) v = 4096;
+  }
+  return v;
+}
+
+// VPS_SORT_ATOMIC=1 forces the one-atomic-per-particle ranking (kept for bucket counts / key ranges the
+// two-level sort does not cover, and as a cross-check in the tests)
+bool sort_force_atomic() {
+  const char* e = getenv("VPS_SORT_ATOMIC");
+  return e && e[0] == '1';
+}
 
 DepLayout dep_layout(int64_t np, int C, const Bricks& b) {
   DepLayout l;
   l.nbricks = (long long)b.nbx * b.nby * b.nbz;
+  SortGeom& g = l.geom;
+  g.cells = (unsigned)b.cells;
+  g.cshift = -1;
+  if ((b.cells & (b.cells - 1)) == 0) {
+    g.cshift = 0;
+    while ((1 << g.cshift) < b.cells) ++g.cshift;
+  }
+  g.nbuckets = l.nbricks;
+  g.gshift = 3;
+  while (((l.nbricks + (1ll << g.gshift) - 1) >> g.gshift) > sort_target_groups()) ++g.gshift;
+  g.ngroups = (int)((l.nbricks + (1ll << g.gshift) - 1) >> g.gshift);
+  g.nchunks = (np + SORT_CHUNK - 1) / SORT_CHUNK;
+  l.two_level = !sort_force_atomic() && g.gshift <= 12 &&
+                (unsigned long long)l.nbricks * (unsigned long long)b.cells < 0xffffffffull;
+  const long long ntable = (long long)g.ngroups * g.nchunks;
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t off = 0;
   l.count = off;   off = align(off + sizeof(unsigned) * l.nbricks);
@@ -416,8 +666,59 @@ DepLayout dep_layout(int64_t np, int C, const Bricks& b) {
   l.keys = off;    off = align(off + (size_t)np * sizeof(unsigned long long));
   l.ranks = off;   off = align(off + (size_t)np * sizeof(unsigned));
   l.records = off; off = align(off + (size_t)np * (C + 1) * sizeof(unsigned));
+  l.table = l.table_start = l.table_tiles = l.rec1 = off;
+  if (l.two_level) {
+    l.table = off;        off = align(off + sizeof(unsigned) * (ntable + 1));
+    l.table_start = off;  off = align(off + sizeof(unsigned) * (ntable + 1));
+    l.table_tiles = off;  off = align(off + sizeof(unsigned) * (scan_tiles(ntable) + 1));
+    l.rec1 = off;         off = align(off + (size_t)np * sort_rec1_words(C) * sizeof(unsigned));
+  }
   l.total = off;
   return l;
+}
+
+// particles -> records {cell-in-bucket, payload[C]} grouped by bucket + start[nbuckets + 1]
+template <typename F, int C, bool RHOV>
+int sort_into_buckets(vps_ctx* ctx, const F* pos, const float* payload, const float* rho, int64_t np, F lcell,
+                      F nsz, const Bricks& b, const DepLayout& l, char* work) {
+  unsigned* count = reinterpret_cast<unsigned*>(work + l.count);
+  unsigned* start = reinterpret_cast<unsigned*>(work + l.start);
+  unsigned* records = reinterpret_cast<unsigned*>(work + l.records);
+  vps_launch_timer tm(ctx, VPS_K_DEPOSIT);
+  if (np == 0) {
+    VPS_HIP_CHECK(ctx, hipMemsetAsync(start, 0, sizeof(unsigned) * (l.nbricks + 1), ctx->stream));
+    return VPS_OK;
+  }
+  if (l.two_level) {
+    const SortGeom& g = l.geom;
+    unsigned* keys = reinterpret_cast<unsigned*>(work + l.keys);
+    unsigned* table = reinterpret_cast<unsigned*>(work + l.table);
+    unsigned* table_start = reinterpret_cast<unsigned*>(work + l.table_start);
+    unsigned* table_tiles = reinterpret_cast<unsigned*>(work + l.table_tiles);
+    unsigned* rec1 = reinterpret_cast<unsigned*>(work + l.rec1);
+    const size_t lds1 = sizeof(unsigned) * g.ngroups;
+    const size_t lds2 = sizeof(unsigned) * ((1u << g.gshift) + FINE_THREADS);
+    hipLaunchKernelGGL(sort_hist_kernel<F>, dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1, ctx->stream, pos,
+                       (long long)np, lcell, nsz, b, g, keys, table);
+    launch_exclusive_scan(ctx->stream, table, (long long)g.ngroups * g.nchunks, table_tiles, table_start);
+    hipLaunchKernelGGL((sort_scatter_kernel<C, RHOV>), dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1,
+                       ctx->stream, keys, payload, rho, (long long)np, g, table_start, rec1);
+    hipLaunchKernelGGL(sort_fine_kernel<C>, dim3((unsigned)g.ngroups), dim3(FINE_THREADS), lds2, ctx->stream, rec1,
+                       g, table_start, start, records);
+  } else {
+    unsigned* tiles = reinterpret_cast<unsigned*>(work + l.tiles);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(work + l.keys);
+    unsigned* ranks = reinterpret_cast<unsigned*>(work + l.ranks);
+    VPS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, sizeof(unsigned) * l.nbricks, ctx->stream));
+    const unsigned pblocks = (unsigned)((np + 255) / 256);
+    hipLaunchKernelGGL(brick_rank_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np, lcell,
+                       nsz, b, count, keys, ranks);
+    launch_exclusive_scan(ctx->stream, count, l.nbricks, tiles, start);
+    hipLaunchKernelGGL((brick_scatter_kernel<C, RHOV>), dim3(pblocks), dim3(256), 0, ctx->stream, keys, ranks,
+                       payload, rho, (long long)np, (unsigned)b.cells, start, records);
+  }
+  VPS_HIP_CHECK(ctx, hipGetLastError());
+  return VPS_OK;
 }
 
 template <typename F, int C, bool RHOV, int EPI>
@@ -431,26 +732,11 @@ int deposit_run(vps_ctx* ctx, const void* pos_v, const float* payload, const flo
   const Bricks b = make_bricks(N, x0, nx, C);
   const DepLayout l = dep_layout(np, C, b);
   char* work = reinterpret_cast<char*>(work_v);
-  unsigned* count = reinterpret_cast<unsigned*>(work + l.count);
   unsigned* start = reinterpret_cast<unsigned*>(work + l.start);
-  unsigned* tiles = reinterpret_cast<unsigned*>(work + l.tiles);
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(work + l.keys);
-  unsigned* ranks = reinterpret_cast<unsigned*>(work + l.ranks);
   unsigned* records = reinterpret_cast<unsigned*>(work + l.records);
-  VPS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, sizeof(unsigned) * l.nbricks, ctx->stream));
-  const unsigned pblocks = (unsigned)((np + 255) / 256);
   const float vol = (float)((Lbox / (double)N) * (Lbox / (double)N) * (Lbox / (double)N));
-  {
-    vps_launch_timer tm(ctx, VPS_K_DEPOSIT);
-    if (np > 0)
-      hipLaunchKernelGGL(brick_rank_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np,
-                         lcell, nsz, b, count, keys, ranks);
-    launch_exclusive_scan(ctx->stream, count, l.nbricks, tiles, start);
-    if (np > 0)
-      hipLaunchKernelGGL((brick_scatter_kernel<C, RHOV>), dim3(pblocks), dim3(256), 0, ctx->stream, keys, ranks,
-                         payload, rho, (long long)np, (unsigned)b.cells, start, records);
-  }
-  VPS_HIP_CHECK(ctx, hipGetLastError());
+  const int rc = sort_into_buckets<F, C, RHOV>(ctx, pos, payload, rho, np, lcell, nsz, b, l, work);
+  if (rc) return rc;
   {
     vps_launch_timer tm(ctx, VPS_K_ALGEBRA);
     const size_t lds = (size_t)C * b.cells * sizeof(float);
@@ -478,28 +764,8 @@ int sort_rhov_records(vps_ctx* ctx, const F* pos, const float* vel, const float*
                       double Lbox, const Bricks& b, char* work, DepLayout* lay) {
   const F lcell = (F)(Lbox / (double)N);
   const F nsz = (F)N;
-  const DepLayout l = dep_layout(np, 4, b);
-  unsigned* count = reinterpret_cast<unsigned*>(work + l.count);
-  unsigned* start = reinterpret_cast<unsigned*>(work + l.start);
-  unsigned* tiles = reinterpret_cast<unsigned*>(work + l.tiles);
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(work + l.keys);
-  unsigned* ranks = reinterpret_cast<unsigned*>(work + l.ranks);
-  unsigned* records = reinterpret_cast<unsigned*>(work + l.records);
-  VPS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, sizeof(unsigned) * l.nbricks, ctx->stream));
-  const unsigned pblocks = (unsigned)((np + 255) / 256);
-  {
-    vps_launch_timer tm(ctx, VPS_K_DEPOSIT);
-    if (np > 0)
-      hipLaunchKernelGGL(brick_rank_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np,
-                         lcell, nsz, b, count, keys, ranks);
-    launch_exclusive_scan(ctx->stream, count, l.nbricks, tiles, start);
-    if (np > 0)
-      hipLaunchKernelGGL((brick_scatter_kernel<4, true>), dim3(pblocks), dim3(256), 0, ctx->stream, keys, ranks,
-                         vel, rho, (long long)np, (unsigned)b.cells, start, records);
-  }
-  VPS_HIP_CHECK(ctx, hipGetLastError());
-  *lay = l;
-  return VPS_OK;
+  *lay = dep_layout(np, 4, b);
+  return sort_into_buckets<F, 4, true>(ctx, pos, vel, rho, np, lcell, nsz, b, *lay, work);
 }
 
 int check_deposit_args(vps_ctx* ctx, const char* who, int64_t np, int N, double Lbox, int x0, int nx) {

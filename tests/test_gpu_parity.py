@@ -35,7 +35,7 @@ def _edge_positions(N, L, dtype):
         np.nextafter(np.arange(0, N + 1) * lc, -np.inf),
         np.nextafter(np.arange(0, N + 1) * lc, np.inf),
         rng.random(2000) * 3 * L - L,                                # outside the box, negative
-        [0.0, -0.0, L, 2 * L, -L, 1e-30, -1e-30, 7.3 * L],
+        [0.0, -0.0, L, 2 * L, -L, 1e-30, -1e-30, 7.3 * L, 1e10, -1e10, 123456.7 * L, 3e7 * L, -2.9e8 * lc],
     ])
     base = base.astype(dtype)
     n = (len(base) // 3) * 3
