@@ -190,8 +190,8 @@ __global__ void __launch_bounds__(256)
 // particles/s) and without 20-byte random writes.
 //   level 1: chunks of SORT_CHUNK particles; per-chunk LDS histogram over coarse groups of
 //            2^gshift consecutive buckets -> table[group][chunk] -> exclusive scan -> each chunk
-//            ranks its particles in LDS and writes {key, payload} into its own contiguous run
-//            of every group
+//            ranks its particles in LDS, stages its records in LDS in group order and streams
+//            {key, payload} into its own contiguous run of every group
 //   level 2: one workgroup per group: LDS histogram over the group's buckets, LDS scan
 //            (-> start[]), second sweep places {loc, payload} at its final slot
 // Slots inside one bucket come out in no particular order (as with the atomic ranks).
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256)
 #define VPS_SORT_THREADS 1024
 #endif
 #ifndef VPS_SORT_ITEMS
-#define VPS_SORT_ITEMS 16
+#define VPS_SORT_ITEMS 2
 #endif
 constexpr int SORT_THREADS = VPS_SORT_THREADS;   // level 1: chunk = SORT_THREADS * SORT_ITEMS particles
 constexpr int SORT_ITEMS = VPS_SORT_ITEMS;
@@ -301,6 +301,107 @@ __global__ void __launch_bounds__(SORT_THREADS)
 #pragma unroll
       for (int c = 0; c < W; ++c) rec[c] = w[c];
     }
+  }
+}
+
+// Exclusive scan of the LDS array a[0..n), n <= 4 * NT, in place; returns the total.
+// `scratch` holds NT/64 words.  All NT threads of the workgroup must call it.
+template <int NT>
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned* a, int n, unsigned* scratch) {
+  const int per = (n + NT - 1) / NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned v[4], mine = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = tid * per + k;
+    v[k] = (k < per && idx < n) ? a[idx] : 0u;
+    mine += v[k];
+  }
+  unsigned inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned up = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += up;
+  }
+  if (lane == 63) scratch[wave] = inc;
+  __syncthreads();
+  unsigned before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    const unsigned t = scratch[w];
+    if (w < wave) before += t;
+    total += t;
+  }
+  unsigned run = before + inc - mine;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = tid * per + k;
+    if (k < per && idx < n) {
+      a[idx] = run;
+      run += v[k];
+    }
+  }
+  __syncthreads();
+  return total;
+}
+
+// Level-1 scatter, LDS-staged: the chunk's records are first placed in LDS in group order, then
+// streamed out word by word, so each (chunk, group) run leaves the CU as contiguous stores instead
+// of 64 scattered dwords per instruction.  Consecutive chunks own adjacent runs of every group:
+// they are dealt to the SAME XCD (blockIdx % 8, speed only) so that its L2 can merge the partly
+// written lines at run boundaries.
+template <int C, bool RHOV>
+__global__ void __launch_bounds__(SORT_THREADS)
+    sort_scatter_staged_kernel(const unsigned* __restrict__ keys, const float* __restrict__ payload,
+                               const float* __restrict__ rho, long long np, SortGeom g,
+                               const unsigned* __restrict__ table_start, unsigned* __restrict__ rec1) {
+  constexpr int W = sort_rec1_words(C);
+  extern __shared__ unsigned sort_lds[];
+  unsigned* gbase = sort_lds;                        // [ngroups] first global slot of this chunk's run
+  unsigned* lstart = gbase + g.ngroups;              // [ngroups] counts, then local exclusive starts
+  unsigned* scratch = lstart + g.ngroups;            // [SORT_THREADS / 64]
+  unsigned* gdest = scratch + SORT_THREADS / 64;     // [SORT_CHUNK] global slot of staged record p
+  unsigned* stage = gdest + SORT_CHUNK;              // [SORT_CHUNK * W]
+  const long long per_xcd = (g.nchunks + 7) / 8;
+  const long long chunk = (long long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (chunk >= g.nchunks) return;
+  for (int i = threadIdx.x; i < g.ngroups; i += SORT_THREADS) {
+    gbase[i] = table_start[(long long)i * g.nchunks + chunk];
+    lstart[i] = 0;
+  }
+  __syncthreads();
+  const long long base = chunk * SORT_CHUNK;
+  unsigned key[SORT_ITEMS], grp[SORT_ITEMS], rk[SORT_ITEMS];
+  float val[SORT_ITEMS][C];
+#pragma unroll
+  for (int k = 0; k < SORT_ITEMS; ++k) {
+    const long long i = base + (long long)k * SORT_THREADS + threadIdx.x;
+    key[k] = (i < np) ? keys[i] : SORT_INVALID;
+    if (key[k] != SORT_INVALID) load_payload<C, RHOV>(payload, rho, i, val[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < SORT_ITEMS; ++k) {
+    if (key[k] != SORT_INVALID) {
+      grp[k] = sort_bucket_of(key[k], g) >> g.gshift;
+      rk[k] = atomicAdd(&lstart[grp[k]], 1u);
+    }
+  }
+  __syncthreads();
+  const unsigned total = block_exclusive_scan<SORT_THREADS>(lstart, g.ngroups, scratch);
+#pragma unroll
+  for (int k = 0; k < SORT_ITEMS; ++k) {
+    if (key[k] != SORT_INVALID) {
+      const unsigned p = lstart[grp[k]] + rk[k];
+      gdest[p] = gbase[grp[k]] + rk[k];
+      stage[p * W] = key[k];
+#pragma unroll
+      for (int c = 0; c < C; ++c) stage[p * W + 1 + c] = __float_as_uint(val[k][c]);
+    }
+  }
+  __syncthreads();
+  for (unsigned t = threadIdx.x; t < total * W; t += SORT_THREADS) {
+    const unsigned rec = t / W, wd = t - rec * W;
+    rec1[(size_t)gdest[rec] * W + wd] = stage[t];
   }
 }
 
@@ -626,11 +727,16 @@ int sort_target_groups() {
   static int v = 0;
   if (!v) {
     const char* e = getenv("VPS_SORT_GROUPS");
-    v = e ? atoi(e) : 1024;
+    v = e ? atoi(e) : 512;
     if (v < 1) v = 1;
     if (v > 4096) v = 4096;
   }
   return v;
+}
+
+bool sort_staged() {
+  const char* e = getenv("VPS_SORT_STAGED");
+  return !e || e[0] != '0';
 }
 
 // VPS_SORT_ATOMIC=1 forces the one-atomic-per-particle ranking (kept for bucket counts / key ranges the
@@ -701,8 +807,20 @@ int sort_into_buckets(vps_ctx* ctx, const F* pos, const float* payload, const fl
     hipLaunchKernelGGL(sort_hist_kernel<F>, dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1, ctx->stream, pos,
                        (long long)np, lcell, nsz, b, g, keys, table);
     launch_exclusive_scan(ctx->stream, table, (long long)g.ngroups * g.nchunks, table_tiles, table_start);
-    hipLaunchKernelGGL((sort_scatter_kernel<C, RHOV>), dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1,
-                       ctx->stream, keys, payload, rho, (long long)np, g, table_start, rec1);
+    const size_t lds_staged = sizeof(unsigned) * (2 * (size_t)g.ngroups + SORT_THREADS / 64 +
+                                                   (size_t)SORT_CHUNK * (1 + sort_rec1_words(C)));
+    if (sort_staged() && lds_staged <= ctx->lds_per_cu) {
+      auto kern = sort_scatter_staged_kernel<C, RHOV>;
+      if (lds_staged > 64 * 1024)
+        VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
+      const unsigned grid = (unsigned)(8 * ((g.nchunks + 7) / 8));
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(SORT_THREADS), lds_staged, ctx->stream, keys, payload, rho,
+                         (long long)np, g, table_start, rec1);
+    } else {
+      hipLaunchKernelGGL((sort_scatter_kernel<C, RHOV>), dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1,
+                         ctx->stream, keys, payload, rho, (long long)np, g, table_start, rec1);
+    }
     hipLaunchKernelGGL(sort_fine_kernel<C>, dim3((unsigned)g.ngroups), dim3(FINE_THREADS), lds2, ctx->stream, rec1,
                        g, table_start, start, records);
   } else {

@@ -75,6 +75,26 @@ def test_deposit_matches_oracle(K, C):
     assert np.allclose(np.concatenate(parts, axis=1), grid, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("env", [{"VPS_SORT_ATOMIC": "1"}, {"VPS_SORT_STAGED": "0"}, {"VPS_SORT_GROUPS": "7"}, {}])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_deposit_sort_variants_are_exact_on_integers(K, monkeypatch, env, dtype):
+    """Every bucket-sort flavour (two-level staged / two-level direct / one atomic per particle) feeds the same
+    records to the accumulation: small-integer payloads make the float32 sums exact, so results must be EQUAL."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(31)
+    N, L, Np = 96, 2.0, 300000                       # N not a power of two: bricks with a ragged edge
+    pos = (rng.random((Np, 3)) * L).astype(dtype)
+    pos[: Np // 4] = pos[: Np // 4] * 0.05 + 0.9     # a clump: long buckets
+    pos[-1000:] = L * 3.5                            # wraps around (periodic)
+    f = rng.integers(1, 4, (Np, 3)).astype(np.float32)
+    ref = orc.deposit_to_grid(f.astype(np.float64), pos, N, L)
+    grid = K.deposit(K.to_device(pos), K.to_device(f), N, L, 0, N).cpu().numpy()
+    assert np.array_equal(grid.transpose(1, 2, 3, 0), ref)
+    part = K.deposit(K.to_device(pos), K.to_device(f), N, L, 40, 24).cpu().numpy()   # a slab: most particles outside
+    assert np.array_equal(part, grid[:, 40:64])
+
+
 def test_deposit_api_and_integer_conservation():
     from vpower import interp
     rng = np.random.default_rng(9)
