@@ -409,70 +409,60 @@ template <int C>
 __global__ void __launch_bounds__(FINE_THREADS)
     sort_fine_kernel(const unsigned* __restrict__ rec1, SortGeom g, const unsigned* __restrict__ table_start,
                      unsigned* __restrict__ start, unsigned* __restrict__ records) {
-  extern __shared__ unsigned sort_lds[];          // [G] cursors, then [FINE_THREADS] scan scratch
+  constexpr int W = sort_rec1_words(C);
+  extern __shared__ unsigned sort_lds[];          // [G] counts -> cursors, then scan scratch
   const int G = 1 << g.gshift;
   unsigned* cur = sort_lds;
-  unsigned* part = sort_lds + G;
+  unsigned* scratch = sort_lds + G;
   const int grp = blockIdx.x;
   const unsigned gs = table_start[(long long)grp * g.nchunks];
   const unsigned ge = table_start[(long long)(grp + 1) * g.nchunks];   // [ngroups*nchunks] = total
   for (int i = threadIdx.x; i < G; i += FINE_THREADS) cur[i] = 0;
   __syncthreads();
-  for (unsigned j = gs + threadIdx.x; j < ge; j += FINE_THREADS)
-    atomicAdd(&cur[sort_bucket_of(rec1[(size_t)j * sort_rec1_words(C)], g) & (G - 1)], 1u);
-  __syncthreads();
-  // exclusive scan of cur[0..G): thread t owns `per` consecutive entries
-  const int per = (G + FINE_THREADS - 1) / FINE_THREADS;
-  unsigned mine = 0;
-  for (int k = 0; k < per; ++k) {
-    const int f = threadIdx.x * per + k;
-    if (f < G) mine += cur[f];
-  }
-  part[threadIdx.x] = mine;
-  __syncthreads();
-  for (int off = 1; off < FINE_THREADS; off <<= 1) {
-    const unsigned add = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0u;
-    __syncthreads();
-    part[threadIdx.x] += add;
-    __syncthreads();
-  }
-  unsigned run = gs + part[threadIdx.x] - mine;
-  for (int k = 0; k < per; ++k) {
-    const int f = threadIdx.x * per + k;
-    if (f < G) {
-      const unsigned cnt = cur[f];
-      cur[f] = run;
-      const long long bucket = (long long)grp * G + f;
-      if (bucket < g.nbuckets) start[bucket] = run;
-      run += cnt;
+  constexpr int U = 4;   // loads of U strides are issued together: the sweeps are latency bound otherwise
+  for (unsigned j0 = gs + threadIdx.x; j0 < ge; j0 += U * FINE_THREADS) {
+    unsigned key[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned j = j0 + u * FINE_THREADS;
+      key[u] = j < ge ? rec1[(size_t)j * W] : SORT_INVALID;
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (key[u] != SORT_INVALID) atomicAdd(&cur[sort_bucket_of(key[u], g) & (G - 1)], 1u);
+  }
+  __syncthreads();
+  block_exclusive_scan<FINE_THREADS>(cur, G, scratch);
+  for (int f = threadIdx.x; f < G; f += FINE_THREADS) {
+    const unsigned at = gs + cur[f];
+    cur[f] = at;
+    const long long bucket = (long long)grp * G + f;
+    if (bucket < g.nbuckets) start[bucket] = at;
   }
   if (grp == g.ngroups - 1 && threadIdx.x == 0) start[g.nbuckets] = ge;
   __syncthreads();
-  for (unsigned j = gs + threadIdx.x; j < ge; j += FINE_THREADS) {
-    constexpr int W = sort_rec1_words(C);
-    const unsigned* src = rec1 + (size_t)j * W;
-    unsigned r[W];
-    if constexpr (W == 2) {
-      const uint2 t = *reinterpret_cast<const uint2*>(src);
-      r[0] = t.x; r[1] = t.y;
-    } else if constexpr (W == 4) {
-      const uint4 t = *reinterpret_cast<const uint4*>(src);
-      r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
-    } else {
+  for (unsigned j0 = gs + threadIdx.x; j0 < ge; j0 += U * FINE_THREADS) {
+    unsigned r[U][W];
 #pragma unroll
-      for (int c = 0; c < W; ++c) r[c] = src[c];
+    for (int u = 0; u < U; ++u) {
+      const unsigned j = j0 + u * FINE_THREADS;
+      r[u][0] = SORT_INVALID;
+      if (j < ge) {
+        const unsigned* src = rec1 + (size_t)j * W;
+#pragma unroll
+        for (int c = 0; c < W; ++c) r[u][c] = src[c];
+      }
     }
-    const unsigned key = r[0];
-    unsigned w[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) w[c] = r[1 + c];
-    const unsigned bucket = sort_bucket_of(key, g);
-    const unsigned slot = atomicAdd(&cur[bucket & (G - 1)], 1u);
-    unsigned* dst = records + (size_t)slot * (C + 1);
-    dst[0] = key - bucket * g.cells;
+    for (int u = 0; u < U; ++u) {
+      if (r[u][0] == SORT_INVALID) continue;
+      const unsigned bucket = sort_bucket_of(r[u][0], g);
+      const size_t slot = atomicAdd(&cur[bucket & (G - 1)], 1u);
+      unsigned* dst = records + slot * W;
+      dst[0] = r[u][0] - bucket * g.cells;
 #pragma unroll
-    for (int c = 0; c < C; ++c) dst[1 + c] = w[c];
+      for (int c = 1; c < W; ++c) dst[c] = r[u][c];
+    }
   }
 }
 
@@ -803,7 +793,7 @@ int sort_into_buckets(vps_ctx* ctx, const F* pos, const float* payload, const fl
     unsigned* table_tiles = reinterpret_cast<unsigned*>(work + l.table_tiles);
     unsigned* rec1 = reinterpret_cast<unsigned*>(work + l.rec1);
     const size_t lds1 = sizeof(unsigned) * g.ngroups;
-    const size_t lds2 = sizeof(unsigned) * ((1u << g.gshift) + FINE_THREADS);
+    const size_t lds2 = sizeof(unsigned) * ((1u << g.gshift) + FINE_THREADS / 64);
     hipLaunchKernelGGL(sort_hist_kernel<F>, dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1, ctx->stream, pos,
                        (long long)np, lcell, nsz, b, g, keys, table);
     launch_exclusive_scan(ctx->stream, table, (long long)g.ngroups * g.nchunks, table_tiles, table_start);

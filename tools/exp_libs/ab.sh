@@ -1,0 +1,8 @@
+# A/B in one box: alternate the two libraries, 3 rounds each
+for r in 1 2 3; do for v in base soa; do
+  if [ $v = base ]; then unset VPS_LIB_PATH; else export VPS_LIB_PATH=$PWD/tools/exp_libs/lib_$v.so; fi
+  for mode in "" "--unfused"; do
+  python bench.py --no-cpu-baseline $mode > gpurun_out/v.json 2>/dev/null; python -c "
+import json; d=json.loads(open('gpurun_out/v.json').read().strip().splitlines()[-1]); print('$v $mode', round(d['ms_per_step'],3), {k:round(x,3) for k,x in d['kernel_ms_per_step'].items()})"
+  done
+done; done
