@@ -166,8 +166,9 @@ def main():
     NH = N // 2
     mean = lambda v: float(np.mean(v)) if len(v) else 0.0
     if fused:
-        # one pencil launch per step: bucket records in (3 passes), three z-transformed fields out
-        z_bytes = 3 * 8.0 * nx * N * (NH + 1) + 3 * 20.0 * Np / world
+        # one pencil launch per step: the bucket records in (20 B per particle, once: the later rounds re-read
+        # them from registers / L2), three z-transformed fields out
+        z_bytes = 3 * 8.0 * nx * N * (NH + 1) + 20.0 * Np / world
         z_per_field = z_bytes / 3
     else:
         z_bytes = 4.0 * nx * N * N + 8.0 * nx * N * (NH + 1)
@@ -188,9 +189,9 @@ def main():
     fft_bytes = 3 * (z_per_field + 16.0 * nx * N * (NH + 1) + 8.0 * (nkz * N + nky) * N)
     traffic = None
     tr_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tr_path) and args.config == "C2" and world == 1 and (dom != "fft_z" or not fused):
+    if os.path.exists(tr_path) and args.config == "C2" and world == 1:
         try:
-            traffic = json.load(open(tr_path)).get(dom)
+            traffic = json.load(open(tr_path)).get("fft_z_fused" if (dom == "fft_z" and fused) else dom)
         except Exception:
             traffic = None
 

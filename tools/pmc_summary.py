@@ -32,7 +32,8 @@ json.dump(summary, open(dst + "_final_pmc_summary.json", "w"), indent=1)
 keymap = {"fft_z_fused": "pencil_fft_z_kernel", "fft_z": "fft_transpose_pass<512, 16, true>",
           "fft_y": "fft_transpose_pass<512, 16, false>", "fft_x": "fft_x_pass<512, 8, 0",
           "brick_accumulate": "brick_accumulate_kernel", "brick_rank": "brick_rank_kernel",
-          "brick_scatter": "brick_scatter_kernel"}
+          "brick_scatter": "brick_scatter_kernel", "sort_hist": "sort_hist_kernel",
+          "sort_scatter": "sort_scatter_staged_kernel", "sort_fine": "sort_fine_kernel"}
 traffic = {"_note": "HBM bytes per MAIN launch at C2 (512^3, 1e7 particles), rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
                     "in separate passes (tools/gpu_profile_round.sh + tools/pmc_summary.py), FETCH_SIZE doubled per "
                     "MI355X_MICROARCH.md section HBM (gfx950 reports half of coalesced streaming reads), KB*1024; raw "
