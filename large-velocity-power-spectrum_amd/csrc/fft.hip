@@ -286,6 +286,44 @@ struct PassParams {
   const cf* tw_r2c;
 };
 
+// Real-input post-processing of a transposed tile image buf[k][t] (NC packed-complex outputs Z per line):
+//   X[k] = 0.5*((Z[k]+conj(Z[NC-k])) - i w^k (Z[k]-conj(Z[NC-k]))),  w = exp(-2 pi i/(2 NC)),
+// X[0] and X[NC] (Nyquist, stored apart) real.  Modes k and NC-k share Z[k], Z[NC-k] and, because
+// w^(NC-k) = -conj(w^k), the product w^k (Z[k]-conj(Z[NC-k])): one thread writes both.
+template <int NC, int T, int NT, bool BOUNDS>
+__device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf* __restrict__ tw_r2c, cf* out,
+                                               long long out_ok, cf* nyq, int nlive) {
+  constexpr int PAIRS = (NC / 2) * T;
+  constexpr int IT = (PAIRS + NT - 1) / NT;
+#pragma unroll 4
+  for (int i = 0; i < IT; ++i) {
+    const int idx = tid + i * NT;
+    if ((PAIRS % NT) != 0 && idx >= PAIRS) break;
+    const int tt = idx % T, k = idx / T;
+    const bool ok = !BOUNDS || tt < nlive;
+    const cf zk = buf[tridx<T>(k, tt)];
+    if (k == 0) {
+      const cf zh = buf[tridx<T>(NC / 2, tt)];
+      if (ok) {
+        out[tt] = make_float2(zk.x + zk.y, 0.f);
+        nyq[tt] = make_float2(zk.x - zk.y, 0.f);
+        out[(long long)(NC / 2) * out_ok + tt] = make_float2(zh.x, -zh.y);
+      }
+    } else {
+      const cf zn = buf[tridx<T>(NC - k, tt)];
+      const cf w = tw_r2c[k];
+      const cf sm = make_float2(zk.x + zn.x, zk.y - zn.y);   // Z[k] + conj(Z[NC-k])
+      const cf d = make_float2(zk.x - zn.x, zk.y + zn.y);    // Z[k] - conj(Z[NC-k])
+      const cf wd = cmul(w, d);
+      if (ok) {
+        // -i * wd = (wd.y, -wd.x);  for NC-k: conj(sm) and -i * conj(wd) = (-wd.y, -wd.x)
+        out[(long long)k * out_ok + tt] = make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));
+        out[(long long)(NC - k) * out_ok + tt] = make_float2(0.5f * (sm.x - wd.y), 0.5f * (-sm.y - wd.x));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------
 // Transposing pass (z pass: REAL=true, y pass: REAL=false).
 // One workgroup transforms T lines a0..a0+T-1 of batch b and writes, for every
@@ -366,29 +404,8 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
       if (a0 + tt < p.A) out[(long long)k * p.out_ok + tt] = buf[tridx<T>(k, tt)];
     }
   } else {
-    // real-input post-processing: X[k] = 0.5*((Z[k]+conj(Z[NC-k])) - i w^k (Z[k]-conj(Z[NC-k])))
-    // with w = exp(-2 pi i/(2 NC)); X[0] and X[NC] (Nyquist) are real.
     cf* nyq = reinterpret_cast<cf*>(p.out_nyq) + (long long)b * p.nyq_ob + a0;
-#pragma unroll 4
-    for (int i = 0; i < RL; ++i) {
-      const int idx = tid + i * NT;
-      const int tt = idx % T, k = idx / T;
-      const cf zk = buf[tridx<T>(k, tt)];
-      cf res;
-      if (k == 0) {
-        res = make_float2(zk.x + zk.y, 0.f);
-        if (a0 + tt < p.A) nyq[tt] = make_float2(zk.x - zk.y, 0.f);
-      } else {
-        const cf zn = buf[tridx<T>(NC - k, tt)];
-        const cf w = p.tw_r2c[k];
-        const cf s = make_float2(zk.x + zn.x, zk.y - zn.y);   // Z[k] + conj(Z[NC-k])
-        const cf d = make_float2(zk.x - zn.x, zk.y + zn.y);   // Z[k] - conj(Z[NC-k])
-        const cf wd = cmul(w, d);
-        // -i * wd = (wd.y, -wd.x)
-        res = make_float2(0.5f * (s.x + wd.y), 0.5f * (s.y - wd.x));
-      }
-      if (a0 + tt < p.A) out[(long long)k * p.out_ok + tt] = res;
-    }
+    r2c_store_tile<NC, T, NT, true>(buf, tid, p.tw_r2c, out, p.out_ok, nyq, p.A - a0);
   }
 }
 
@@ -539,25 +556,7 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
     __syncthreads();
     cf* out = p.out[c] + (long long)x * NC * N + y0;
     cf* nyq = p.nyq[c] + (long long)x * N + y0;
-#pragma unroll 4
-    for (int i = 0; i < RL; ++i) {
-      const int idx = tidc + i * NT;
-      const int tt = idx % TP, k = idx / TP;
-      const cf zk = buf[tridx<TP>(k, tt)];
-      cf res;
-      if (k == 0) {
-        res = make_float2(zk.x + zk.y, 0.f);
-        nyq[tt] = make_float2(zk.x - zk.y, 0.f);
-      } else {
-        const cf zn = buf[tridx<TP>(NC - k, tt)];
-        const cf w = p.tw_r2c[k];
-        const cf sm = make_float2(zk.x + zn.x, zk.y - zn.y);   // Z[k] + conj(Z[NC-k])
-        const cf d = make_float2(zk.x - zn.x, zk.y + zn.y);    // Z[k] - conj(Z[NC-k])
-        const cf wd = cmul(w, d);
-        res = make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));
-      }
-      out[(long long)k * N + tt] = res;
-    }
+    r2c_store_tile<NC, TP, NT, false>(buf, tidc, p.tw_r2c, out, N, nyq, TP);
   }
 }
 
