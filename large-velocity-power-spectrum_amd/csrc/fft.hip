@@ -464,24 +464,25 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
   const unsigned s = p.start[pencil], e = p.start[pencil + 1];
   if constexpr (PI::TWLDS)
     for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
-  // The first KR*NT records of the bucket are fetched ONCE into registers (the loads fly while
-  // the accumulator is zeroed); only unusually full pencils touch the records again.
+  // The cells of the first KR*NT records of the bucket stay in registers; the value each round adds
+  // (rho, then rho v_c) is fetched one round ahead, so the loads fly behind the previous round's FFT.
+  // Only unusually full pencils read records inside a round (tail loops below).
   constexpr int KR = VPS_PENCIL_KR;
   unsigned rloc[KR];
-  float rq[KR][3], rrho[KR];
+  float rval[KR];
+  auto fetch = [&](int word) {   // record word 1..3: rho v_c, 4: rho
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const unsigned j = s + tid + k * NT;
+      if (j < e) rval[k] = __uint_as_float(p.records[(size_t)j * 5 + word]);
+    }
+  };
 #pragma unroll
   for (int k = 0; k < KR; ++k) {
     const unsigned j = s + tid + k * NT;
-    rloc[k] = 0xffffffffu;
-    if (j < e) {
-      const unsigned* rec = p.records + (size_t)j * 5;
-      rloc[k] = rec[0];
-      rq[k][0] = __uint_as_float(rec[1]);
-      rq[k][1] = __uint_as_float(rec[2]);
-      rq[k][2] = __uint_as_float(rec[3]);
-      rrho[k] = __uint_as_float(rec[4]);
-    }
+    rloc[k] = (j < e) ? p.records[(size_t)j * 5] : 0xffffffffu;
   }
+  fetch(p.divide ? 4 : 1 + p.chan[0]);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int R0 = PI::R0, NB0 = RL / R0;
   float2 scale[RL];   // per stage-0 input cell pair: 1/rho (0 where empty) or Lcell^3
@@ -490,7 +491,8 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KR; ++k)
-      if (rloc[k] != 0xffffffffu) atomicAdd(&acc[rloc[k]], rrho[k]);
+      if (rloc[k] != 0xffffffffu) atomicAdd(&acc[rloc[k]], rval[k]);
+    fetch(1 + p.chan[0]);
     for (unsigned j = s + tid + KR * NT; j < e; j += NT) {
       const unsigned* rec = p.records + (size_t)j * 5;
       atomicAdd(&acc[rec[0]], __uint_as_float(rec[4]));
@@ -522,12 +524,9 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
     __syncthreads();
     const int chn = p.chan[c];
 #pragma unroll
-    for (int k = 0; k < KR; ++k) {
-      if (rloc[k] != 0xffffffffu) {
-        const float qv = chn == 0 ? rq[k][0] : (chn == 1 ? rq[k][1] : rq[k][2]);
-        atomicAdd(&acc[rloc[k]], qv);
-      }
-    }
+    for (int k = 0; k < KR; ++k)
+      if (rloc[k] != 0xffffffffu) atomicAdd(&acc[rloc[k]], rval[k]);
+    if (c + 1 < p.ncomp) fetch(1 + p.chan[c + 1]);
     for (unsigned j = s + tid + KR * NT; j < e; j += NT) {
       const unsigned* rec = p.records + (size_t)j * 5;
       atomicAdd(&acc[rec[0]], __uint_as_float(rec[1 + chn]));
