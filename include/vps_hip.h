@@ -207,6 +207,15 @@ int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0,
               const void* in_dev, int nseg, int64_t seg_stride, int mode,
               double* psum_dev, unsigned long long* nsample_dev, void* out_dev);
 
+/* Binning x pass of a VECTOR field: the ncomp (1..3) component spectra in_devs[c] (same layout and
+ * arguments as vps_fft_x) are transformed line by line, their |F|^2 SUMMED, and the sum binned once
+ * (mode 0 when count != 0, else mode 3) -- the component sum of _vector_power (interp.py:1386,
+ * parallel_optimized.py:131-137) fused with _pair_power/_hist_sample.  in_devs is a HOST array of
+ * device pointers. */
+int vps_fft_x_bin(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0,
+                  const void* const* in_devs, int ncomp, int nseg, int64_t seg_stride, int count,
+                  double* psum_dev, unsigned long long* nsample_dev);
+
 /* Single-GPU convenience: full |F(k)|^2 binning of one real field.
  * field_dev [N][N][N] float32 is preserved; work_dev: vps_power_workspace_bytes(N). */
 size_t vps_power_workspace_bytes(int N);

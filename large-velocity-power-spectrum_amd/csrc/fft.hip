@@ -519,6 +519,9 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
     // component loop (they cost more registers than the 1/rho table and an occupancy step)
     int lc = l, tc = t, tidc = tid;
     asm volatile("" : "+v"(lc), "+v"(tc), "+v"(tidc));
+    lc &= L - 1;   // give the value ranges back to the compiler (address folding needs them)
+    tc &= TP - 1;
+    tidc &= NT - 1;
     __syncthreads();   // rho / previous component's transposed image fully consumed
     for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
     __syncthreads();
@@ -591,7 +594,10 @@ int launch_pencil(vps_ctx* ctx, const PencilParams& p, long long npencils) {
 // Persistent workgroups loop over tiles of T lines.
 // ------------------------------------------------------------------------------
 struct XParams {
-  const cf* in;
+  const cf* in;            // component 0
+  const cf* in1;           // components 1, 2 of a vector field (binning modes, ncomp > 1)
+  const cf* in2;
+  int ncomp;
   cf* out;
   long long nlines, line0;
   int N, kz0;
@@ -695,9 +701,9 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
       }
     }
   };
-  auto load_line = [&]() {
+  auto load_line = [&](int c, int l) {   // l: the lane index (callers inside loops pass an opaque copy)
     constexpr int R = PI::R0, NB = RL / R;
-    const cf* base = p.in + li * p.seglen;
+    const cf* base = (c == 0 ? p.in : (c == 1 ? p.in1 : p.in2)) + li * p.seglen;
 #pragma unroll
     for (int m = 0; m < NB; ++m)
 #pragma unroll
@@ -714,7 +720,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   };
   if ((long long)blockIdx.x < ntiles) {
     locate_line(blockIdx.x);
-    load_line();
+    load_line(0, l);
   }
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // line bookkeeping of THIS tile (v already holds, or is receiving, its inputs)
@@ -722,8 +728,10 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
     const bool live_cur = live, mirrored_cur = mirrored, partner_cur = has_partner;
     const double k2y_cur = k2y, k2z_cur = k2z;
     const unsigned wz_cur = wz;
-    exchange_sync<WSYNC>();  // previous tile's readers are done with the line buffers
-    fft_from_regs<NC, WSYNC>(v, line, tw, l);
+    if constexpr (MODE != 0) {
+      exchange_sync<WSYNC>();  // previous tile's readers are done with the line buffers
+      fft_from_regs<NC, WSYNC>(v, line, tw, l);
+    }
     if constexpr (MODE == 1) {
       if (live_cur) {
         cf* o = p.out + li_cur * (long long)NC;
@@ -745,21 +753,46 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
       // of RL kx values: along kx the shell index moves monotonically (per half line), so a
       // lane accumulates each run of equal bins in registers and issues one LDS float64
       // atomic per run, and the lanes of a wave-instruction hit different bins.
+      // The components of a vector field are transformed one after the other and their |F|^2 summed in
+      // registers (the reference bins the SUM, interp.py:1372-1421), so the shell search and the LDS
+      // atomics below run once per line, not once per component.  As soon as a transform has been
+      // squared its registers take the next loads: the next component of this tile, or the first of
+      // the next tile, which then fly while this tile is binned.
+      float pacc[RL];
+      for (int c = 0; c < p.ncomp; ++c) {
+        // opaque copy of the lane index: keeps the LDS / global addresses of this loop from being
+        // hoisted out of it as ~50 extra live registers (an occupancy step)
+        int lc = l;
+        asm volatile("" : "+v"(lc));
+        lc &= L - 1;   // give the value range back to the compiler (address folding needs it)
+        exchange_sync<WSYNC>();  // previous readers are done with the line buffers
+        fft_from_regs<NC, WSYNC>(v, line, tw, lc);
+#pragma unroll
+        for (int i = 0; i < RL; ++i) {
+          const float a = v[i].x * v[i].x + v[i].y * v[i].y;
+          pacc[i] = (c == 0) ? a : pacc[i] + a;
+        }
+        if (c + 1 < p.ncomp) {
+          load_line(c + 1, lc);
+        } else if (tile + gridDim.x < ntiles) {
+          locate_line(tile + gridDim.x);
+          load_line(0, lc);
+        }
+      }
       float* pw = reinterpret_cast<float*>(line);
       if constexpr (PI::R1 > 1) exchange_sync<WSYNC>();  // last exchange fully consumed
       constexpr int CH = FAST ? H : RL;              // chunk length; one pad word per chunk
+      {
+        int lw = l;   // opaque again: 16 store addresses recomputed per tile instead of kept live
+        asm volatile("" : "+v"(lw));
+        lw &= L - 1;
 #pragma unroll
-      for (int i = 0; i < RL; ++i) {
-        const int k = out_index<NC>(l, i);
-        pw[k + k / CH] = v[i].x * v[i].x + v[i].y * v[i].y;
+        for (int i = 0; i < RL; ++i) {
+          const int k = out_index<NC>(lw, i);
+          pw[k + k / CH] = pacc[i];
+        }
       }
       exchange_sync<WSYNC>();
-      // v is dead from here on: start fetching the next tile's lines so that the loads are
-      // in flight while this tile is binned
-      if (tile + gridDim.x < ntiles) {
-        locate_line(tile + gridDim.x);
-        load_line();
-      }
       if constexpr (FAST) {
         if (live_cur && !mirrored_cur) {
           const unsigned w = wz_cur * (partner_cur ? 2u : 1u);
@@ -862,7 +895,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
     if constexpr (MODE != 0) {
       if (tile + gridDim.x < ntiles) {
         locate_line(tile + gridDim.x);
-        load_line();
+        load_line(0, l);
       }
     }
   }
@@ -1233,9 +1266,9 @@ int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, cons
 
 extern "C" {
 
-int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const void* in_dev,
-              int nseg, int64_t seg_stride, int mode, double* psum_dev,
-              unsigned long long* nsample_dev, void* out_dev) {
+static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const void* in_dev,
+                      const void* in1_dev, const void* in2_dev, int ncomp, int nseg, int64_t seg_stride,
+                      int mode, double* psum_dev, unsigned long long* nsample_dev, void* out_dev) {
   if (!ctx) return VPS_ERR_ARG;
   if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096]", N);
   if (nlines < 0 || !in_dev) return vps_fail(ctx, VPS_ERR_ARG, "bad line count / null input");
@@ -1246,6 +1279,9 @@ int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const
   if (rc) return rc;
   XParams p{};
   p.in = reinterpret_cast<const cf*>(in_dev);
+  p.in1 = reinterpret_cast<const cf*>(in1_dev);
+  p.in2 = reinterpret_cast<const cf*>(in2_dev);
+  p.ncomp = ncomp;
   p.out = reinterpret_cast<cf*>(out_dev);
   p.nlines = nlines;
   p.line0 = line0;
@@ -1287,6 +1323,24 @@ int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const
     return vps_fail(ctx, VPS_ERR_ARG, "mode must be 0..4");
   }
   return rc;
+}
+
+int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const void* in_dev,
+              int nseg, int64_t seg_stride, int mode, double* psum_dev,
+              unsigned long long* nsample_dev, void* out_dev) {
+  return fft_x_impl(ctx, N, nlines, line0, kz0, in_dev, in_dev, in_dev, 1, nseg, seg_stride, mode, psum_dev,
+                    nsample_dev, out_dev);
+}
+
+int vps_fft_x_bin(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const void* const* in_devs,
+                  int ncomp, int nseg, int64_t seg_stride, int count, double* psum_dev,
+                  unsigned long long* nsample_dev) {
+  if (!ctx) return VPS_ERR_ARG;
+  if (ncomp < 1 || ncomp > 3 || !in_devs) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_x_bin: ncomp must be 1..3");
+  for (int c = 0; c < ncomp; ++c)
+    if (!in_devs[c]) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_x_bin: null component %d", c);
+  return fft_x_impl(ctx, N, nlines, line0, kz0, in_devs[0], in_devs[ncomp > 1 ? 1 : 0], in_devs[ncomp > 2 ? 2 : 0],
+                    ncomp, nseg, seg_stride, count ? 0 : 3, psum_dev, nsample_dev, nullptr);
 }
 
 int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, double* psum_dev,

@@ -60,6 +60,8 @@ SYMBOLS = (
     ("vps_fft_workspace_bytes", C.c_size_t, (C.c_int, C.c_int)),
     ("vps_fft_zy", C.c_int, (_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp)),
     ("vps_fft_x", C.c_int, (_vp, C.c_int, _i64, _i64, C.c_int, _vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp)),
+    ("vps_fft_x_bin", C.c_int, (_vp, C.c_int, _i64, _i64, C.c_int, C.POINTER(_vp), C.c_int, C.c_int, _i64, C.c_int,
+                               _vp, _vp)),
     ("vps_power_workspace_bytes", C.c_size_t, (C.c_int,)),
     ("vps_power_bin", C.c_int, (_vp, C.c_int, _vp, _vp, _vp, _vp)),
     ("vps_rfft3", C.c_int, (_vp, C.c_int, _vp, _vp, _vp)),

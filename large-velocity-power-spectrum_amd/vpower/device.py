@@ -19,6 +19,7 @@ CPU tensors by the test-suite's oracle-backed stand-in; the product default is
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -324,6 +325,14 @@ class HipKernels:
                                      seg_stride, 0 if count else 3, self._ptr(psum, torch.float64),
                                      self._ptr(nsample, torch.int64), None))
 
+    def fft_x_bin_multi(self, comps, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True):
+        """x pass of up to three component spectra, |F|^2 summed over the components, binned once."""
+        self._stream()
+        ptrs = (C.c_void_p * len(comps))(*[self._ptr(c, torch.complex64).value for c in comps])
+        self._chk(self.lib.vps_fft_x_bin(self.ctx, N, nlines, line0, kz0, ptrs, len(comps), nseg, seg_stride,
+                                         1 if count else 0, self._ptr(psum, torch.float64),
+                                         self._ptr(nsample, torch.int64)))
+
     def fft_x_write(self, lines, N, nlines, nseg, seg_stride, out):
         self._stream()
         self._chk(self.lib.vps_fft_x(self.ctx, N, nlines, 0, 0, self._ptr(lines, torch.complex64), nseg,
@@ -506,13 +515,24 @@ class PowerPipeline:
         for f in fields:
             spec, nyq = k.fft_zy(f, N, nx)
             pending.append((self.comm.all_to_all_start(spec), self.comm.all_to_all_start(nyq)))
-        for i, (hs, hq) in enumerate(pending):
-            c = count and i == 0
-            spec = self.comm.all_to_all_finish(hs)
-            nyq = self.comm.all_to_all_finish(hq)
-            k.fft_x_bin(spec, N, nkz * N, 0, r * nkz, G, nkz * N * nx, psum, nsample, count=c)
-            k.fft_x_bin(nyq, N, nky, r * nky, N // 2, G, nky * nx, psum, nsample, count=c)
+        self._bin_exchanged(pending, psum, nsample, count)
         return psum, nsample
+
+    def _bin_exchanged(self, pending, psum, nsample, count):
+        """x pass + shell sums of exchanged spectra.  Up to three components at a time go through ONE
+        launch that sums their |F|^2 before the shell search (what the reference does on the grid,
+        interp.py:1386, 1474-1477); VPS_X_PER_COMPONENT=1 bins every component on its own instead."""
+        N, nx, G, r = self.N, self.nx, self.comm.world, self.comm.rank
+        k = self.k
+        nkz, nky = N // 2 // G, N // G
+        done = [(self.comm.all_to_all_finish(hs), self.comm.all_to_all_finish(hq)) for hs, hq in pending]
+        group = 1 if os.environ.get("VPS_X_PER_COMPONENT") == "1" else 3
+        for i in range(0, len(done), group):
+            c = count and i == 0
+            specs = [d[0] for d in done[i:i + group]]
+            nyqs = [d[1] for d in done[i:i + group]]
+            k.fft_x_bin_multi(specs, N, nkz * N, 0, r * nkz, G, nkz * N * nx, psum, nsample, count=c)
+            k.fft_x_bin_multi(nyqs, N, nky, r * nky, N // 2, G, nky * nx, psum, nsample, count=c)
 
     def accumulate_spectra(self, spec, nyq, psum=None, nsample=None, count=True):
         """Like `accumulate`, for fields that already went through the z and y passes
@@ -526,12 +546,7 @@ class PowerPipeline:
         nkz, nky = N // 2 // G, N // G
         pending = [(self.comm.all_to_all_start(spec[i]), self.comm.all_to_all_start(nyq[i]))
                    for i in range(spec.shape[0])]
-        for i, (hs, hq) in enumerate(pending):
-            c = count and i == 0
-            s = self.comm.all_to_all_finish(hs)
-            q = self.comm.all_to_all_finish(hq)
-            k.fft_x_bin(s, N, nkz * N, 0, r * nkz, G, nkz * N * nx, psum, nsample, count=c)
-            k.fft_x_bin(q, N, nky, r * nky, N // 2, G, nky * nx, psum, nsample, count=c)
+        self._bin_exchanged(pending, psum, nsample, count)
         return psum, nsample
 
     def finish(self, psum, nsample):

@@ -42,6 +42,10 @@ class OracleKernels:
                 for g in range(nseg)]
         return np.concatenate(segs, axis=1)
 
+    def fft_x_bin_multi(self, comps, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True):
+        for i, lines in enumerate(comps):
+            self.fft_x_bin(lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=count and i == 0)
+
     def fft_x_bin(self, lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True):
         Nb, k2, thr = self.binning
         assert Nb == N

@@ -400,6 +400,24 @@ def test_fused_deposit_fft_matches_unfused(K, N, nx, x0, quantity, flags):
         assert float((nyq[c] - n_ref).abs().max()) / scale < 2e-5
 
 
+def test_component_summed_binning_equals_per_component(K, monkeypatch):
+    """One x-pass launch that sums |F|^2 over the three components before binning (default) against
+    three launches that bin every component on its own: same counts, sums equal to float32 rounding."""
+    from vpower import device
+    N, L = 128, 1.0
+    rng = np.random.default_rng(5)
+    fields = [K.to_device(rng.standard_normal((N, N, N)).astype(np.float32)) for _ in range(3)]
+    pipe = device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False))
+    a = pipe.finish(*pipe.accumulate(fields))
+    monkeypatch.setenv("VPS_X_PER_COMPONENT", "1")
+    b = pipe.finish(*pipe.accumulate(fields))
+    assert np.array_equal(a[:, 3], b[:, 3])
+    assert np.allclose(a[:, 2], b[:, 2], rtol=1e-6, atol=0)
+    two = pipe.finish(*pipe.accumulate(fields[:2]))          # ncomp = 2
+    monkeypatch.delenv("VPS_X_PER_COMPONENT")
+    assert np.allclose(pipe.finish(*pipe.accumulate(fields[:2]))[:, 2], two[:, 2], rtol=1e-6, atol=0)
+
+
 def test_fused_pipeline_against_oracle(K):
     from vpower import device
     N, L, Np = 64, 1.0, 60000
