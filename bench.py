@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="separate deposit and z-pass kernels (grid through HBM)")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra instrumented steps for the roofline")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="diagnostic: time ONE rank's share of a G-rank slab decomposition on one GPU "
+                         "(x-slab N/G, segmented x pass, exchanges skipped; the spectrum is not meaningful)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,6 +102,18 @@ def main():
     N, Np, off = synth.CONFIGS[args.config]
     L = 1.0
     comm = device.SlabComm()
+    if args.emulate_ranks > 1 and world == 1:
+        class _OneOfG(device.SlabComm):
+            """rank 0 of G without peers: the local z/y output stands in for the exchanged buffer
+            (same sizes and segment layout), reductions are local"""
+            def __init__(self, G):
+                super().__init__(enabled=False)
+                self.world, self.rank = G, 0
+            def all_to_all_start(self, send):
+                return send, None
+            def all_reduce_sum(self, t):
+                return t
+        comm = _OneOfG(args.emulate_ranks)
     pipe = device.PowerPipeline(N, L, kernels=K, comm=comm, flavour="library")
     nx, x0 = pipe.nx, pipe.x0
 
@@ -109,7 +124,7 @@ def main():
     grid = K.empty((3, nx, N, N), torch.float32)
     psum = K.zeros((pipe.nbins,), torch.float64)
     nsample = K.zeros((pipe.nbins,), torch.int64)
-    G = world
+    G = comm.world
     nkz, nky = N // 2 // G, N // G
 
     fused = K.fused_supported(N, device.VELOCITY) and not args.unfused
@@ -151,7 +166,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    cells = float(N) ** 3 * 3            # grid cells x components per step (whole job)
+    cells = float(N) ** 3 * 3 * world / comm.world   # grid cells x components per step (whole job; emulation: one rank's share)
 
     # ---- per-kernel durations (HIP events on the library's stream), untimed extra steps ----
     K.timing(True)
@@ -168,7 +183,7 @@ def main():
     if fused:
         # one pencil launch per step: the bucket records in (20 B per particle, once: the later rounds re-read
         # them from registers / L2), three z-transformed fields out
-        z_bytes = 3 * 8.0 * nx * N * (NH + 1) + 20.0 * Np / world
+        z_bytes = 3 * 8.0 * nx * N * (NH + 1) + 20.0 * Np / G
         z_per_field = z_bytes / 3
     else:
         z_bytes = 4.0 * nx * N * N + 8.0 * nx * N * (NH + 1)
@@ -176,7 +191,7 @@ def main():
     alg_bytes = {   # algorithmic HBM bytes per main launch (DESIGN.md "Kernels")
         "fft_z": z_bytes,
         "fft_y": 16.0 * nx * N * NH,
-        "fft_x": 8.0 * nkz * N * N,
+        "fft_x": 3 * 8.0 * nkz * N * N,   # one launch transforms and bins the three components
     }
     avg_ms = {"fft_z": mean(per["fft_z"]), "fft_y": mean(main_y), "fft_x": mean(main_x),
               # gridding stage: rank+scan+scatter ("deposit") and, unfused, brick accumulate+write ("algebra");
@@ -189,7 +204,7 @@ def main():
     fft_bytes = 3 * (z_per_field + 16.0 * nx * N * (NH + 1) + 8.0 * (nkz * N + nky) * N)
     traffic = None
     tr_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tr_path) and args.config == "C2" and world == 1:
+    if os.path.exists(tr_path) and args.config == "C2" and world == 1 and comm.world == 1:
         try:
             traffic = json.load(open(tr_path)).get("fft_z_fused" if (dom == "fft_z" and fused) else dom)
         except Exception:
@@ -206,7 +221,8 @@ def main():
         "config": {"workload": "%s: %d^3 grid, %d particles, velocity P(k), NGP deposit, library binning"
                                % (args.config, N, Np), "grid": N, "particles": Np,
                    "path": "fused deposit+z pass (pencil buckets)" if fused else "deposit -> grid -> z pass",
-                   "parallelism": "x-slab x%d, 1 all-to-all/field" % world},
+                   "parallelism": ("x-slab x%d, 1 all-to-all/field" % world) if comm.world == world else
+                                  ("EMULATED rank 0 of %d on one GPU, exchanges skipped (diagnostic)" % comm.world)},
         "particles_per_s": Np / (avg_ms["deposit"] * 1e-3) if avg_ms["deposit"] > 0 else None,
         "fft_cells_per_s": cells / (fft_ms * 1e-3) / 1.0 if fft_ms > 0 else None,
         "fft_stage": {"ms_per_step": fft_ms, "algorithmic_GBs": fft_bytes / (fft_ms * 1e-3) / 1e9 if fft_ms else None,
@@ -216,7 +232,7 @@ def main():
                      "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": avg_ms[dom]},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and comm.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         assert np.isfinite(tab[:, 2]).all() and tab[:, 3].sum() > 0
