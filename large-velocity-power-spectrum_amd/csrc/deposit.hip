@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(256)
       const unsigned* rec = records + (size_t)j * (C + 1);
       const unsigned loc = rec[0];
 #pragma unroll
-      for (int c = 0; c < C; ++c) atomicAdd(&tile[c * cells + loc], __uint_as_float(rec[1 + c]));
+      for (int c = 0; c < C; ++c) atomicAdd(&tile[c * cells + loc], __uint_as_float(rec[1 + c]));   // (vps_lds_add: slower here)
     }
     // bucket bounds of the next brick: in flight during the stream-out below
     const long long nb = brick + gridDim.x;

@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
 // Fused deposit + field algebra + z pass ("pencil" kernel).  A pencil is the TP z-lines
 // (x, y0..y0+TP-1, all z) that one z-pass tile transforms.  The deposit stage has sorted
 // the particle records {cell-in-pencil, rho vx, rho vy, rho vz, rho} by pencil
-// (deposit.hip), so one workgroup accumulates rho of its pencil in LDS (float atomics), keeps
+// (deposit.hip), so one workgroup accumulates rho of its pencil in LDS (vps_lds_add), keeps
 // 1/rho of its own stage-0 cells in registers, then per component accumulates rho*v in the same
 // LDS region, forms v = rho v / rho (or p = rho v Lcell^3) as it loads the FFT's stage-0 inputs,
 // transforms and writes B[x][kz][y] -- the real-space grid is never written to or read from
@@ -462,6 +462,8 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
   const unsigned pencil = blockIdx.x;
   const int x = pencil / p.nby, y0 = (pencil % p.nby) * TP;
   const unsigned s = p.start[pencil], e = p.start[pencil + 1];
+  // more than two particles per cell on average: hot cells are likely, take the native atomics (vps_lds_add)
+  const bool crowded = (e - s) > 2u * (unsigned)ACC;
   if constexpr (PI::TWLDS)
     for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
   // The cells of the first KR*NT records of the bucket stay in registers; the value each round adds
@@ -491,11 +493,11 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KR; ++k)
-      if (rloc[k] != 0xffffffffu) atomicAdd(&acc[rloc[k]], rval[k]);
+      if (rloc[k] != 0xffffffffu) vps_lds_add(&acc[rloc[k]], rval[k], crowded);
     fetch(1 + p.chan[0]);
     for (unsigned j = s + tid + KR * NT; j < e; j += NT) {
       const unsigned* rec = p.records + (size_t)j * 5;
-      atomicAdd(&acc[rec[0]], __uint_as_float(rec[4]));
+      vps_lds_add(&acc[rec[0]], __uint_as_float(rec[4]), crowded);
     }
     __syncthreads();
     const float* r = acc + t * N;
@@ -528,11 +530,11 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
     const int chn = p.chan[c];
 #pragma unroll
     for (int k = 0; k < KR; ++k)
-      if (rloc[k] != 0xffffffffu) atomicAdd(&acc[rloc[k]], rval[k]);
+      if (rloc[k] != 0xffffffffu) vps_lds_add(&acc[rloc[k]], rval[k], crowded);
     if (c + 1 < p.ncomp) fetch(1 + p.chan[c + 1]);
     for (unsigned j = s + tid + KR * NT; j < e; j += NT) {
       const unsigned* rec = p.records + (size_t)j * 5;
-      atomicAdd(&acc[rec[0]], __uint_as_float(rec[1 + chn]));
+      vps_lds_add(&acc[rec[0]], __uint_as_float(rec[1 + chn]), crowded);
     }
     __syncthreads();
     // stage-0 inputs straight from the accumulator: z[j] = f[2j] + i f[2j+1]
