@@ -433,12 +433,9 @@ struct PencilParams {
   const cf* tw_r2c;
 };
 
-// tuning knobs (measured at 512^3 / 1024^3): 4 waves/SIMD needs <= 128 VGPRs; 2 preloaded record groups
+// tuning knob (measured at 512^3 / 1024^3): 4 waves/SIMD needs <= 128 VGPRs
 #ifndef VPS_PENCIL_MINW
 #define VPS_PENCIL_MINW 4
-#endif
-#ifndef VPS_PENCIL_KR
-#define VPS_PENCIL_KR 2
 #endif
 
 template <int NC, int TP>
@@ -469,7 +466,9 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
   // The cells of the first KR*NT records of the bucket stay in registers; the value each round adds
   // (rho, then rho v_c) is fetched one round ahead, so the loads fly behind the previous round's FFT.
   // Only unusually full pencils read records inside a round (tail loops below).
-  constexpr int KR = VPS_PENCIL_KR;
+  // register-resident record groups: enough for a typical bucket (~1.2 x mean occupancy at the bench
+  // densities) -- 3 x 256 threads at 512^3, 2 x 512 at 1024^3 (measured optimum each)
+  constexpr int KR = NT >= 512 ? 2 : (NT >= 256 ? 3 : 4);
   unsigned rloc[KR];
   float rval[KR];
   auto fetch = [&](int word) {   // record word 1..3: rho v_c, 4: rho
