@@ -412,13 +412,16 @@ class SlabComm:
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.backend = dist.get_backend(group) if self.enabled else None
+        # VPS_FORCE_COLLECTIVES=1: issue the collectives even in a one-rank group (exercises the RCCL
+        # plumbing -- complex views, async work handles -- on a single GPU; tests only)
+        self.force = self.enabled and os.environ.get("VPS_FORCE_COLLECTIVES") == "1"
 
     def all_to_all_start(self, send):
         """Begin an equal-split all-to-all along dim 0 of a contiguous tensor.  Returns
         (recv, work); `all_to_all_finish` makes `recv` usable on the current stream.  With
         RCCL the exchange runs on the communicator's stream, so kernels issued in between
         (the z/y passes of the next field, the x pass of the previous one) overlap it."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return send, None
         if send.is_cuda and self.backend != "nccl":
             # gloo rehearsal on a GPU box: stage through host memory (synchronous)
@@ -452,7 +455,7 @@ class SlabComm:
         return self.all_to_all_finish(self.all_to_all_start(send))
 
     def all_reduce_sum(self, t):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return t
         if t.is_cuda and self.backend != "nccl":
             h = t.cpu()

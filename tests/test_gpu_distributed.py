@@ -60,3 +60,48 @@ def test_two_ranks_one_gpu_hip_kernels(tmp_path, world, N):
         tab = np.load(tmp_path / f"tab_{r}.npy")
         assert np.array_equal(tab[:, 3], ref[:, 3])
         assert np.allclose(tab[:, 2], ref[:, 2], rtol=2e-5, atol=0)
+
+
+def _rccl_worker(rank, port, N, Np, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "large-velocity-power-spectrum_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["VPS_FORCE_COLLECTIVES"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from vpower import device, synth
+        K = device.default_kernels(0)
+        pos, vel, mass, dens = synth.particles(33, Np, 1.0)
+        comm = device.SlabComm()
+        assert comm.backend == "nccl" and comm.force
+        pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=comm)
+        d = [K.to_device(a) for a in (pos, vel, dens)]
+        spec, nyq = K.deposit_fft_zy(d[0], d[1], d[2], N, 1.0, 0, N, device.VELOCITY)
+        tab = pipe.finish(*pipe.accumulate_spectra(spec, nyq))     # fused path: complex all-to-alls + all-reduces over RCCL
+        fields = K.deposit_field(d[0], d[1], d[2], N, 1.0, 0, N, device.VELOCITY)
+        tab2 = pipe.finish(*pipe.accumulate([fields[0], fields[1], fields[2]]))
+        np.save(os.path.join(out_dir, "tab_rccl.npy"), np.stack([tab, tab2]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_single_rank(tmp_path):
+    """The nccl (= RCCL) code path of SlabComm -- complex tensors as real views, asynchronous
+    all_to_all_single, all-reduce of the float64 / int64 shell accumulators -- driven on the one GPU of
+    the test box by forcing the collectives in a one-rank group."""
+    import torch.multiprocessing as mp
+    from vpower import synth
+    N, Np = 64, 100000
+    mp.spawn(_rccl_worker, args=(_free_port(), N, Np, str(tmp_path)), nprocs=1, join=True)
+    pos, vel, mass, dens = synth.particles(33, Np, 1.0)
+    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
+    v, m = orc.vm_from_vec_grid(orc.deposit_to_grid_fast(vec, pos, N, 1.0), 1.0 / N, zero_empty=True)
+    ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, 1.0 / N, "velocity")
+    for tab in np.load(tmp_path / "tab_rccl.npy"):
+        assert np.array_equal(tab[:, 3], ref[:, 3])
+        assert np.allclose(tab[:, 2], ref[:, 2], rtol=2e-5, atol=0)
