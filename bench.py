@@ -122,8 +122,8 @@ def main():
     dpos, dvel, drho = K.to_device(pos), K.to_device(vel), K.to_device(dens)
     del pos, vel, mass, dens
     grid = K.empty((3, nx, N, N), torch.float32)
-    psum = K.zeros((pipe.nbins,), torch.float64)
-    nsample = K.zeros((pipe.nbins,), torch.int64)
+    psum, nsample = pipe.new_accumulators()      # two views of one buffer: one fill, one D2H copy per step
+    acc_buf = pipe._acc_buf
     G = comm.world
     nkz, nky = N // 2 // G, N // G
 
@@ -133,8 +133,7 @@ def main():
         nyq3 = K.empty((3, N, nx), torch.complex64)
 
     def step():
-        psum.zero_()
-        nsample.zero_()
+        acc_buf.zero_()
         if fused:
             # deposit + v = rho v / rho + z pass in one kernel (pencil buckets), then the y passes
             K.deposit_fft_zy(dpos, dvel, drho, N, L, x0, nx, device.VELOCITY, spec=spec3, nyq=nyq3)

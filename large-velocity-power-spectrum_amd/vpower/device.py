@@ -508,8 +508,7 @@ class PowerPipeline:
         k = self.k
         k.set_binning(*self._binning)
         if psum is None:
-            psum = k.zeros((self.nbins,), torch.float64)
-            nsample = k.zeros((self.nbins,), torch.int64)
+            psum, nsample = self.new_accumulators()
         nkz = N // 2 // G      # kz rows per rank after the exchange
         nky = N // G           # Nyquist-plane ky rows per rank
         # issue every field's z/y passes and start its exchange right away, then run the x
@@ -544,13 +543,19 @@ class PowerPipeline:
         k = self.k
         k.set_binning(*self._binning)
         if psum is None:
-            psum = k.zeros((self.nbins,), torch.float64)
-            nsample = k.zeros((self.nbins,), torch.int64)
+            psum, nsample = self.new_accumulators()
         nkz, nky = N // 2 // G, N // G
         pending = [(self.comm.all_to_all_start(spec[i]), self.comm.all_to_all_start(nyq[i]))
                    for i in range(spec.shape[0])]
         self._bin_exchanged(pending, psum, nsample, count)
         return psum, nsample
+
+    def new_accumulators(self):
+        """Zeroed shell sums (float64) and shell counts (int64) as two views of ONE device buffer, so that a
+        step clears them with one fill and `finish` brings them to the host with one copy."""
+        buf = self.k.zeros((2 * self.nbins,), torch.float64)
+        self._acc_buf = buf
+        return buf[: self.nbins], buf[self.nbins:].view(torch.int64)
 
     def finish(self, psum, nsample):
         """Reduce over ranks and build the reference's (nbins,4) table
@@ -558,8 +563,15 @@ class PowerPipeline:
         before the 4 pi k^2 factor."""
         self.comm.all_reduce_sum(psum)
         self.comm.all_reduce_sum(nsample)
-        ps = psum.cpu().numpy() * (0.5 * self.const ** 2)
-        ns = nsample.cpu().numpy()
+        buf = getattr(self, "_acc_buf", None)
+        if (buf is not None and psum.data_ptr() == buf.data_ptr()
+                and nsample.data_ptr() == buf.data_ptr() + 8 * self.nbins):
+            host = buf.cpu()                         # one device-to-host copy for both accumulators
+            ps = host[: self.nbins].numpy() * (0.5 * self.const ** 2)
+            ns = host[self.nbins:].view(torch.int64).numpy()
+        else:
+            ps = psum.cpu().numpy() * (0.5 * self.const ** 2)
+            ns = nsample.cpu().numpy()
         with np.errstate(invalid="ignore", divide="ignore"):
             P = ps / ns
         if self.flavour == "library":
