@@ -329,7 +329,8 @@ __device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf*
 // One workgroup transforms T lines a0..a0+T-1 of batch b and writes, for every
 // output index k, the T results to T contiguous complex slots out[b][k][a0..].
 // ------------------------------------------------------------------------------
-template <int NC, int T, bool REAL>
+// NTEMP: non-temporal loads and stores (y pass of images up to ~0.75 GB: -4..-9 % there, +2..+5 % on larger ones)
+template <int NC, int T, bool REAL, bool NTEMP = false>
 __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
     fft_transpose_pass(const PassParams p) {
   typedef PlanInfo<NC> PI;
@@ -381,8 +382,14 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
 #pragma unroll
       for (int m = 0; m < NB; ++m)
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-          v[m * R + r] = live ? src[l + L * m + r * (NC / R)] : make_float2(0.f, 0.f);
+        for (int r = 0; r < R; ++r) {
+          if constexpr (NTEMP) {
+            const double raw = live ? __builtin_nontemporal_load(reinterpret_cast<const double*>(&src[l + L * m + r * (NC / R)])) : 0.0;
+            v[m * R + r] = *reinterpret_cast<const cf*>(&raw);
+          } else {
+            v[m * R + r] = live ? src[l + L * m + r * (NC / R)] : make_float2(0.f, 0.f);
+          }
+        }
     }
   }
   __syncthreads();  // twiddle image visible
@@ -401,7 +408,14 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
     for (int i = 0; i < RL; ++i) {
       const int idx = tid + i * NT;
       const int tt = idx % T, k = idx / T;
-      if (a0 + tt < p.A) out[(long long)k * p.out_ok + tt] = buf[tridx<T>(k, tt)];
+      if (a0 + tt < p.A) {
+        const cf val = buf[tridx<T>(k, tt)];
+        if constexpr (NTEMP)
+          __builtin_nontemporal_store(*reinterpret_cast<const double*>(&val),
+                                      reinterpret_cast<double*>(&out[(long long)k * p.out_ok + tt]));
+        else
+          out[(long long)k * p.out_ok + tt] = val;
+      }
     }
   } else {
     cf* nyq = reinterpret_cast<cf*>(p.out_nyq) + (long long)b * p.nyq_ob + a0;
@@ -966,6 +980,10 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
   typedef PlanInfo<NC> PI;
   const size_t lds = transpose_lds_bytes<NC, T>();
   auto kern = fft_transpose_pass<NC, T, REAL>;
+  if constexpr (!REAL) {
+    const double image_bytes = 8.0 * (double)p.A * (double)p.B * (double)NC;
+    if (image_bytes <= 768.0 * 1048576.0) kern = fft_transpose_pass<NC, T, REAL, true>;
+  }
   if (lds > 64 * 1024)
     VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
