@@ -420,15 +420,16 @@ __global__ void __launch_bounds__(FINE_THREADS)
   for (int i = threadIdx.x; i < G; i += FINE_THREADS) cur[i] = 0;
   __syncthreads();
   constexpr int U = 4;   // loads of U strides are issued together: the sweeps are latency bound otherwise
-  // The level-1 records are read with streaming loads: they are dead after this kernel, and what should
-  // stay in the caches are the final records it writes (the accumulation kernel reads them next:
-  // pencil kernel -10 % for +4 % here).  Streaming hints on the level-1 scatter itself cost 35 %.
+  // The second sweep reads the level-1 records with streaming loads: they are dead after it, and what
+  // should stay in the caches are the final records it writes (the accumulation kernel reads them next:
+  // pencil kernel -10 %).  The first sweep keeps plain loads so that the second finds the lines.
+  // Streaming hints on the level-1 scatter itself cost 35 %.
   for (unsigned j0 = gs + threadIdx.x; j0 < ge; j0 += U * FINE_THREADS) {
     unsigned key[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const unsigned j = j0 + u * FINE_THREADS;
-      key[u] = j < ge ? __builtin_nontemporal_load(&rec1[(size_t)j * W]) : SORT_INVALID;
+      key[u] = j < ge ? rec1[(size_t)j * W] : SORT_INVALID;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
