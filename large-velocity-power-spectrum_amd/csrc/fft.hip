@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
       for (int m = 0; m < NB; ++m)
 #pragma unroll
         for (int r = 0; r < R; ++r)
-          v[m * R + r] = live ? src[l + L * m + r * (NC / R)] : make_float2(0.f, 0.f);
+          v[m * R + r] = live ? load_stream(&src[l + L * m + r * (NC / R)]) : make_float2(0.f, 0.f);
     } else {
       const cf* src = reinterpret_cast<const cf*>(p.in) + (long long)b * p.in_sb +
                       (long long)(a0 + t) * p.in_sa;
