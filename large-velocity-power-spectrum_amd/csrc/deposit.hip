@@ -4,17 +4,19 @@
 // (:199-213) and the elementwise steps of ann_interp_to_field /
 // BoxField.{momentum,kinetic_energy}_power (:272-273, 523-525, 546).
 //
-// Deposition is a two-level bucket scheme built for HBM3E + 160 KiB LDS:
-//   1. count   : one pass over the particles, histogram of BRICK ids (a brick is a
-//                bx*by*bz block of cells whose C float channels fit a 64 KiB LDS tile);
-//   2. scan    : exclusive prefix sum of the brick counts;
-//   3. scatter : second pass, each particle's record {cell-in-brick, payload[C]} is
-//                written into its brick's contiguous bucket (slot = start + rank, the
-//                rank being what the counting atomic of pass 1 returned);
-//   4. bricks  : one workgroup per brick adds its bucket into an LDS tile with LDS
-//                float atomics and then streams the WHOLE tile out with full-width
-//                coalesced stores (rows of bz cells), applying the field algebra
-//                (v = rho v / rho, momentum, kinetic energy) on the way out.
+// Deposition is a bucket scheme built for HBM3E + 160 KiB LDS:
+//   1. sort    : the particles' records {cell-in-bucket, payload[C]} are grouped by BUCKET (a brick of
+//                bx*by*bz cells whose C float channels fit an LDS tile, or a z-pass pencil on the
+//                fused path) by a two-level LDS bucket sort -- chunk histograms, one scan, LDS-staged
+//                runs, one workgroup per coarse group (see "Two-level bucket sort" below).  No global
+//                atomic per particle, no random 20-byte writes.  A one-atomic-per-particle ranking
+//                (brick_rank_kernel / brick_scatter_kernel) remains for bucket counts or key ranges
+//                the sort does not cover.
+//   2. buckets : one workgroup per bucket adds its records into an LDS tile and then either streams
+//                the WHOLE tile out with full-width coalesced stores (rows of bz cells), applying the
+//                field algebra (v = rho v / rho, momentum, kinetic energy) on the way out
+//                (brick_accumulate_kernel), or feeds it straight into the z-pass FFT
+//                (pencil_fft_z_kernel, fft.hip).
 // Every cell of the slab is therefore written exactly once by plain stores: there is no
 // grid memset, no global float atomic and no separate algebra pass.
 //
