@@ -506,10 +506,6 @@ __device__ __forceinline__ void algebra_cell(float a, float b, float c, float rh
   }
 }
 
-__host__ __device__ inline int quantity_channels(int quantity) {
-  return quantity == VPS_ENERGY ? 1 : (quantity == VPS_VM ? 4 : 3);
-}
-
 // QUANT is the (compile-time) quantity of the algebra epilogue; NOUT its channel count
 template <int C, int EPI, int QUANT>
 __global__ void __launch_bounds__(256)

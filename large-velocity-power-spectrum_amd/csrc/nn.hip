@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256)
   const int ncy = cy1 - cy0 + 1, ncz = cz1 - cz0 + 1;
   const int ncol = (cx1 - cx0 + 1) * ncy;
   const bool fits = range[1] >= 0 && ncol <= 64 && ncol * (ncz + 1) <= NN_MAXCELL;
-  if (fits && threadIdx.x < ncol) {
+  if (fits && (int)threadIdx.x < ncol) {
     const long long row = ((long long)(cx0 + threadIdx.x / ncy) * M + (cy0 + threadIdx.x % ncy)) * M;
     colbase[threadIdx.x + 1] = start[row + cz1 + 1] - start[row + cz0];
   }
@@ -376,7 +376,7 @@ struct NnLayout {
   int M;
 };
 
-NnLayout nn_layout(int64_t np, int is_f64) {
+NnLayout nn_layout(int64_t np, int /*is_f64*/) {
   NnLayout l;
   l.M = nn_grid_side(np);
   l.ncell = (long long)l.M * l.M * l.M;
