@@ -116,12 +116,13 @@ int vps_deposit_field(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const f
                       const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx,
                       int quantity, int flags, float* fields_dev, void* work_dev);
 
-/* The shortest form of stages A1 + A3 + the z and y passes of B for a vector quantity
- * (VPS_VELOCITY, VPS_MOMENTUM; N in [64, 1024]): particle records are bucketed by "pencil"
- * (one z-pass tile: x, 16 y-lines, all z), each pencil is accumulated in LDS, turned into
- * v = rho v / rho (or p) and transformed along z without the real-space grid ever touching
- * HBM; then the y pass.  Outputs, per component c = 0..2, the arrays vps_fft_zy produces:
- *   spec_dev [3][N/2][N][nx] complex64,  nyq_dev [3][N][nx] complex64.
+/* The shortest form of stages A1 + A3 + the z and y passes of B (VPS_VELOCITY, VPS_MOMENTUM,
+ * VPS_ENERGY; N in [64, 2048]): particle records are bucketed by "pencil" (one z-pass tile:
+ * x, 16 y-lines, all z), each pencil is accumulated in LDS, turned into v = rho v / rho (or p, or
+ * E = m |v|^2) and transformed along z without the real-space grid ever touching HBM; then the
+ * y pass.  Outputs, per component c (3 for velocity / momentum, 1 for energy), the arrays
+ * vps_fft_zy produces:
+ *   spec_dev [ncomp][N/2][N][nx] complex64,  nyq_dev [ncomp][N][nx] complex64.
  * work_dev: vps_deposit_fft_zy_workspace_bytes(np, N, nx).                          */
 int vps_deposit_fft_zy_supported(vps_ctx* ctx, int N, int quantity);
 size_t vps_deposit_fft_zy_workspace_bytes(int64_t np, int N, int nx);

@@ -962,7 +962,7 @@ int vps_deposit_field(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const f
 
 int vps_deposit_fft_zy_supported(vps_ctx* ctx, int N, int quantity) {
   if (!ctx) return 0;
-  return (quantity == VPS_VELOCITY || quantity == VPS_MOMENTUM) && vps_pencil_supported(ctx, N) ? 1 : 0;
+  return (quantity == VPS_VELOCITY || quantity == VPS_MOMENTUM || quantity == VPS_ENERGY) && vps_pencil_supported(ctx, N) ? 1 : 0;
 }
 
 size_t vps_deposit_fft_zy_workspace_bytes(int64_t np, int N, int nx) {
@@ -994,7 +994,8 @@ int vps_deposit_fft_zy(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const 
   const int chan[3] = {0, bug ? 0 : 1, bug ? 0 : 2};
   return vps_fft_pencil_zy(ctx, N, nx, reinterpret_cast<const unsigned*>(work + l.records),
                            reinterpret_cast<const unsigned*>(work + l.start), 3, chan,
-                           quantity == VPS_VELOCITY ? 1 : 0, (float)(lc * lc * lc), spec_dev, nyq_dev,
+                           quantity == VPS_MOMENTUM ? 0 : 1, quantity == VPS_ENERGY ? 1 : 0, (float)(lc * lc * lc),
+                           spec_dev, nyq_dev,
                            work + l.total);
 }
 

@@ -449,6 +449,7 @@ struct PencilParams {
   int ncomp;
   int chan[3];               // record channel (0..2) feeding component c
   int divide;                // 1: v = q / rho (0 where rho == 0);  0: p = q * vol
+  int energy;                // 1: ONE output field E = vol * sum_c q_c^2 / rho (= mass * |v|^2, interp.py:546)
   float vol;
   cf* out[3];                // B_c[x][kz][y]
   cf* nyq[3];                // BN_c[x][y]
@@ -461,7 +462,7 @@ struct PencilParams {
 #define VPS_PENCIL_MINW 4
 #endif
 
-template <int NC, int TP>
+template <int NC, int TP, bool ENERGY = false>
 __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_fft_z_kernel(const PencilParams p) {
   typedef PlanInfo<NC> PI;
   constexpr int L = PI::L, RL = PI::RL, NT = TP * L, N = 2 * NC;
@@ -538,6 +539,7 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
     for (int i = 0; i < RL; ++i) scale[i] = make_float2(p.vol, p.vol);
   }
 
+  cf e2[ENERGY ? RL : 1];   // sum over the components of (rho v_c)^2 per stage-0 cell (ENERGY only)
   for (int c = 0; c < p.ncomp; ++c) {
     // opaque copies: keeps the compiler from hoisting ~50 loop-invariant LDS addresses out of the
     // component loop (they cost more registers than the 1/rho table and an occupancy step)
@@ -570,8 +572,18 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
           const int j = lc + L * m + rr * (NC / R0);
           const float2 qq = *reinterpret_cast<const float2*>(q + 2 * j);
           const float2 sc = scale[m * R0 + rr];
-          v[m * R0 + rr] = make_float2(qq.x * sc.x, qq.y * sc.y);
+          if constexpr (ENERGY) {
+            // kinetic energy: the three rho*v_c rounds only add up q_c^2; E = vol * sum / rho after the last
+            cf& a2 = e2[m * R0 + rr];
+            a2 = (c == 0) ? make_float2(qq.x * qq.x, qq.y * qq.y) : make_float2(a2.x + qq.x * qq.x, a2.y + qq.y * qq.y);
+            if (c + 1 == p.ncomp) v[m * R0 + rr] = make_float2(a2.x * sc.x * p.vol, a2.y * sc.y * p.vol);
+          } else {
+            v[m * R0 + rr] = make_float2(qq.x * sc.x, qq.y * sc.y);
+          }
         }
+    }
+    if constexpr (ENERGY) {
+      if (c + 1 < p.ncomp) continue;   // (the barrier at the top of the loop protects the accumulator)
     }
     __syncthreads();   // accumulator of this component consumed: its memory becomes FFT scratch
     constexpr bool WSYNC = (L <= 64) && (64 % L == 0);
@@ -580,8 +592,9 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
 #pragma unroll
     for (int i = 0; i < RL; ++i) buf[tridx<TP>(out_index<NC>(lc, i), tc)] = v[i];
     __syncthreads();
-    cf* out = p.out[c] + (long long)x * NC * N + y0;
-    cf* nyq = p.nyq[c] + (long long)x * N + y0;
+    const int oc = ENERGY ? 0 : c;
+    cf* out = p.out[oc] + (long long)x * NC * N + y0;
+    cf* nyq = p.nyq[oc] + (long long)x * N + y0;
     r2c_store_tile<NC, TP, NT, false>(buf, tidc, p.tw_r2c, out, N, nyq, TP);
   }
 }
@@ -600,7 +613,7 @@ int launch_pencil(vps_ctx* ctx, const PencilParams& p, long long npencils) {
   typedef PlanInfo<NC> PI;
   const size_t lds = pencil_lds_bytes<NC>();
   if (lds > ctx->lds_per_cu) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "pencil kernel needs %zu B LDS", lds);
-  auto kern = pencil_fft_z_kernel<NC, PENCIL_TP>;
+  auto kern = p.energy ? pencil_fft_z_kernel<NC, PENCIL_TP, true> : pencil_fft_z_kernel<NC, PENCIL_TP, false>;
   if (lds > 64 * 1024)
     VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1253,7 +1266,7 @@ bool vps_pencil_supported(vps_ctx* ctx, int N) {
 
 // records sorted by pencil -> ncomp half spectra after the z and y passes
 int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, const unsigned* start,
-                      int ncomp, const int* chan, int divide, float vol, void* spec_dev, void* nyq_dev,
+                      int ncomp, const int* chan, int divide, int energy, float vol, void* spec_dev, void* nyq_dev,
                       void* bwork_dev) {
   const int NH = N / 2;
   vps_fft_tables tz;
@@ -1274,6 +1287,7 @@ int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, cons
     p.nyq[c] = p.out[c] + bfield;
   }
   p.divide = divide;
+  p.energy = energy;
   p.vol = vol;
   p.tw_stage = tz.tw_stage;
   p.tw_r2c = tz.tw_r2c;
@@ -1290,7 +1304,8 @@ int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, cons
   if (rc) return rc;
   cf* spec = reinterpret_cast<cf*>(spec_dev);
   cf* nyq = reinterpret_cast<cf*>(nyq_dev);
-  for (int c = 0; c < ncomp; ++c) {
+  const int nout = energy ? 1 : ncomp;
+  for (int c = 0; c < nout; ++c) {
     rc = fft_y_of(ctx, N, nx, p.out[c], p.nyq[c], spec + (size_t)c * NH * N * nx, nyq + (size_t)c * N * nx);
     if (rc) return rc;
   }

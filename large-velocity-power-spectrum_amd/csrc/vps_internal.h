@@ -76,7 +76,7 @@ void vps_fft_free_tables(vps_ctx* ctx);
 int vps_pencil_tp(void);
 bool vps_pencil_supported(vps_ctx* ctx, int N);
 int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, const unsigned* start,
-                      int ncomp, const int* chan, int divide, float vol, void* spec_dev, void* nyq_dev,
+                      int ncomp, const int* chan, int divide, int energy, float vol, void* spec_dev, void* nyq_dev,
                       void* bwork_dev);
 
 // ---- LDS floating-point accumulation ---------------------------------------------------------

@@ -259,13 +259,14 @@ class HipKernels:
         return bool(self.lib.vps_deposit_fft_zy_supported(self.ctx, int(N), int(quantity)))
 
     def deposit_fft_zy(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, spec=None, nyq=None):
-        """Fused deposit + field algebra + z/y passes for a vector quantity:
-        -> spec [3, N/2, N, nx], nyq [3, N, nx] (complex64)."""
+        """Fused deposit + field algebra + z/y passes:
+        -> spec [ncomp, N/2, N, nx], nyq [ncomp, N, nx] (complex64); ncomp = 1 for ENERGY, else 3."""
         self._stream()
+        ncomp = 1 if quantity == ENERGY else 3
         if spec is None:
-            spec = self.empty((3, N // 2, N, nx), torch.complex64)
+            spec = self.empty((ncomp, N // 2, N, nx), torch.complex64)
         if nyq is None:
-            nyq = self.empty((3, N, nx), torch.complex64)
+            nyq = self.empty((ncomp, N, nx), torch.complex64)
         work = self.workspace("fused", self.lib.vps_deposit_fft_zy_workspace_bytes(pos.shape[0], N, nx))
         self._chk(self.lib.vps_deposit_fft_zy(self.ctx, self._ptr(pos), self._pos_kind(pos),
                                               self._ptr(vel, torch.float32), self._ptr(rho, torch.float32),

@@ -143,8 +143,9 @@ class GasParticles:
         k = _kernels()
         vel = k.to_device(np.asarray(self.v), torch.float32)
         rho = k.to_device(np.asarray(self.density), torch.float32)
-        grid = k.deposit_field(_pos_tensor(k, self.pos), vel, rho, Nsize, self.Lbox, 0, Nsize, _dev.VM)
-        return BoxField._from_device(grid, self.Lbox / Nsize)
+        # The grid itself is built on first use: `deposit_to_field(N).spctrm(...)`, the usual composition, goes
+        # from the particles to P(k) through the fused deposit + z-pass kernel and never writes a grid.
+        return BoxField._from_particles((_pos_tensor(k, self.pos), vel, rho), Nsize, self.Lbox)
 
     def total_mass(self) -> float:
         return np.sum(self.mass)
@@ -186,12 +187,32 @@ class BoxField:
         self.Lbox = self.Nsize * Lcell
         return self
 
+    @classmethod
+    def _from_particles(cls, src, Nsize, Lbox):
+        """Lazy NGP field of the device particle arrays src = (pos, vel, rho)."""
+        self = cls.__new__(cls)
+        self.Lcell = Lbox / Nsize
+        self._host = {}
+        self._chans = None
+        self._src = src
+        self.Nsize = Nsize
+        self.Lbox = Lbox               # as given (Nsize * Lcell may differ in the last bit)
+        return self
+
+    def _materialise(self):
+        src = getattr(self, "_src", None)
+        if src is not None and self._chans is None and not self._host:
+            self._chans = _kernels().deposit_field(src[0], src[1], src[2], self.Nsize, self.Lbox, 0, self.Nsize, _dev.VM)
+        self._src = None
+
     def _get(self, name, ch):
+        self._materialise()
         if name not in self._host:
             self._host[name] = self._chans[ch].cpu().numpy().astype(np.float64)
         return self._host[name]
 
     def _set(self, name, value):
+        self._materialise()
         self._host[name] = value
         if self._chans is not None:       # host copy is now authoritative
             for n, c in (("vx", 0), ("vy", 1), ("vz", 2), ("mass", 3)):
@@ -204,6 +225,7 @@ class BoxField:
     mass = property(lambda s: s._get("mass", 3), lambda s, v: s._set("mass", v))
 
     def _device_chans(self, k):
+        self._materialise()
         if self._chans is None:
             host = np.stack([np.asarray(self._host[n], dtype=np.float32) for n in ("vx", "vy", "vz", "mass")])
             self._chans = k.to_device(host)
@@ -261,9 +283,21 @@ class BoxField:
         """Binned spectrum, P multiplied by 4 pi k^2 (interp.py:560-595): z/y/x FFT passes
         with |F|^2 and the shell histogram fused into the last pass."""
         k = _kernels()
-        fields = self._fields(k, quantity)
         pipe = _dev.PowerPipeline(self.Nsize, self.Lbox, kernels=k, comm=_dev.SlabComm(enabled=False),
                                   flavour="library", kmin=kmin, kmax=kmax, kres=kres)
+        src = getattr(self, "_src", None)
+        if quantity not in _dev.QUANTITY:
+            raise Exception("""Unrecognized physical quantity name.
+        Supported: 'velocity', 'momentum', 'energy'.""")
+        if src is not None and k.fused_supported(self.Nsize, _dev.QUANTITY[quantity]):
+            # particle-backed field: particles -> z/y-transformed spectra in one go (no grid in HBM)
+            flags = _dev.FLAG_REFERENCE_MOMENTUM_BUG if (quantity == "momentum" and REFERENCE_COMPAT["momentum_bug"]) else 0
+            spec, nyq = k.deposit_fft_zy(src[0], src[1], src[2], self.Nsize, self.Lbox, 0, self.Nsize,
+                                         _dev.QUANTITY[quantity], flags)
+            tab = pipe.finish(*pipe.accumulate_spectra(spec, nyq))
+            tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2
+            return PowerSpectrum(tab)
+        fields = self._fields(k, quantity)
         return PowerSpectrum(pipe.spectrum(fields))
 
     # -- diagnostics (interp.py:639-666) ----------------------------------------------

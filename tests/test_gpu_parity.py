@@ -383,7 +383,7 @@ def test_config1_full_size_against_oracle():
 def test_fused_deposit_fft_matches_unfused(K, N, nx, x0, quantity, flags):
     from vpower import device
     q = device.QUANTITY[quantity]
-    assert K.fused_supported(N, q) and not K.fused_supported(N, device.ENERGY) and not K.fused_supported(4096, q)
+    assert K.fused_supported(N, q) and K.fused_supported(N, device.ENERGY) and not K.fused_supported(4096, q)
     rng = np.random.default_rng(N + nx)
     Np = 150000
     pos = rng.random((Np, 3)).astype(np.float32)
@@ -416,6 +416,43 @@ def test_component_summed_binning_equals_per_component(K, monkeypatch):
     two = pipe.finish(*pipe.accumulate(fields[:2]))          # ncomp = 2
     monkeypatch.delenv("VPS_X_PER_COMPONENT")
     assert np.allclose(pipe.finish(*pipe.accumulate(fields[:2]))[:, 2], two[:, 2], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("N,nx,x0", [(64, 64, 0), (256, 64, 64), (1024, 16, 480)])
+def test_fused_energy_matches_unfused(K, N, nx, x0):
+    from vpower import device
+    rng = np.random.default_rng(N + 3)
+    Np = 200000
+    pos = rng.random((Np, 3)).astype(np.float32)
+    pos[: Np // 5] = pos[: Np // 5] * 0.1 + 0.45
+    d = [K.to_device(pos), K.to_device(rng.standard_normal((Np, 3)).astype(np.float32)),
+         K.to_device(np.exp(rng.standard_normal(Np)).astype(np.float32))]
+    field = K.deposit_field(d[0], d[1], d[2], N, 1.0, x0, nx, device.ENERGY)
+    spec, nyq = K.deposit_fft_zy(d[0], d[1], d[2], N, 1.0, x0, nx, device.ENERGY)
+    assert spec.shape[0] == 1
+    s_ref, n_ref = K.fft_zy(field[0], N, nx)
+    scale = float(s_ref.abs().pow(2).mean().sqrt())
+    assert float((spec[0] - s_ref).abs().max()) / scale < 2e-5
+    assert float((nyq[0] - n_ref).abs().max()) / scale < 2e-5
+
+
+def test_particle_backed_boxfield_takes_the_fused_path_and_matches_the_grid_path():
+    """gp.deposit_to_field(N).spctrm(q) goes from the particles to P(k) without a grid; touching a grid
+    attribute afterwards materialises the field, and the classic grid path gives the same spectrum."""
+    from vpower import interp
+    N, L, Np = 64, 1.0, 80000
+    pos, vel, mass, dens = synth(91, Np, L)
+    gp = interp.GasParticles(pos, mass, dens, vel, L)
+    for q in ("velocity", "momentum", "energy"):
+        box = gp.deposit_to_field(N)
+        assert box._src is not None and box._chans is None
+        fast = box.spctrm(q)
+        assert box._src is not None and box._chans is None          # still no grid
+        _ = box.mass                                                # materialise
+        assert box._src is None and box._chans is not None
+        slow = box.spctrm(q)
+        assert np.array_equal(fast.Nsample, slow.Nsample)
+        assert np.allclose(fast.Psum, slow.Psum, rtol=2e-5, atol=0)
 
 
 def test_fused_pipeline_against_oracle(K):
