@@ -47,6 +47,9 @@ enum vps_quantity { VPS_VELOCITY = 0, VPS_MOMENTUM = 1, VPS_ENERGY = 2,
 /* flags for vps_field_algebra */
 #define VPS_FLAG_REFERENCE_MOMENTUM_BUG 1 /* py=pz=vx*mass as interp.py:523-525 */
 #define VPS_FLAG_INPUT_IS_VM 2             /* channels already hold vx,vy,vz,mass (a BoxField) */
+#define VPS_FLAG_REUSE_SORT 4              /* vps_deposit_fft_zy: work_dev still holds the bucketed records of the
+                                              previous call with the SAME particles, N, Lbox, x0, nx -- skip the sort
+                                              (several quantities of one snapshot) */
 
 /* ---- lifecycle ---------------------------------------------------------- */
 int vps_create(vps_ctx** out, int device_id);

@@ -986,9 +986,13 @@ int vps_deposit_fft_zy(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const 
   const Bricks b = make_pencils(N, x0, nx, vps_pencil_tp());
   char* work = reinterpret_cast<char*>(work_dev);
   DepLayout l;
-  rc = pos_is_f64 ? sort_rhov_records<double>(ctx, reinterpret_cast<const double*>(pos_dev), vel_dev, rho_dev, np, N, Lbox, b, work, &l)
-                  : sort_rhov_records<float>(ctx, reinterpret_cast<const float*>(pos_dev), vel_dev, rho_dev, np, N, Lbox, b, work, &l);
-  if (rc) return rc;
+  if (flags & VPS_FLAG_REUSE_SORT) {
+    l = dep_layout(np, 4, b);     // the caller vouches that the records of the previous call are still there
+  } else {
+    rc = pos_is_f64 ? sort_rhov_records<double>(ctx, reinterpret_cast<const double*>(pos_dev), vel_dev, rho_dev, np, N, Lbox, b, work, &l)
+                    : sort_rhov_records<float>(ctx, reinterpret_cast<const float*>(pos_dev), vel_dev, rho_dev, np, N, Lbox, b, work, &l);
+    if (rc) return rc;
+  }
   const double lc = Lbox / (double)N;
   const int bug = (quantity == VPS_MOMENTUM) && (flags & VPS_FLAG_REFERENCE_MOMENTUM_BUG);
   const int chan[3] = {0, bug ? 0 : 1, bug ? 0 : 2};

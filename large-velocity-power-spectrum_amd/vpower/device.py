@@ -30,6 +30,7 @@ VELOCITY, MOMENTUM, ENERGY, VM = 0, 1, 2, 3
 QUANTITY = {"velocity": VELOCITY, "momentum": MOMENTUM, "energy": ENERGY}
 FLAG_REFERENCE_MOMENTUM_BUG = 1
 FLAG_INPUT_IS_VM = 2
+FLAG_REUSE_SORT = 4
 
 
 # --------------------------------------------------------------------------- #
@@ -258,7 +259,7 @@ class HipKernels:
     def fused_supported(self, N, quantity):
         return bool(self.lib.vps_deposit_fft_zy_supported(self.ctx, int(N), int(quantity)))
 
-    def deposit_fft_zy(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, spec=None, nyq=None):
+    def deposit_fft_zy(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, spec=None, nyq=None, reuse_sort=None):
         """Fused deposit + field algebra + z/y passes:
         -> spec [ncomp, N/2, N, nx], nyq [ncomp, N, nx] (complex64); ncomp = 1 for ENERGY, else 3."""
         self._stream()
@@ -268,11 +269,26 @@ class HipKernels:
         if nyq is None:
             nyq = self.empty((ncomp, N, nx), torch.complex64)
         work = self.workspace("fused", self.lib.vps_deposit_fft_zy_workspace_bytes(pos.shape[0], N, nx))
+        # reuse_sort (a token returned by an earlier call): several quantities of the SAME particle tensors -- the
+        # bucketed records of that call are still in the workspace if nothing else has used it since, and then
+        # only the first call sorts.  The token pins the tensors (their addresses cannot be recycled) and
+        # records their in-place modification counters; any mismatch silently sorts again.
+        state = (pos, vel, rho, pos._version, vel._version, rho._version, int(N), float(Lbox), int(x0), int(nx),
+                 work.data_ptr())
+        last = getattr(self, "_fused_token", None)
+        if (reuse_sort is not None and reuse_sort is last and all(a is b for a, b in zip(last[:3], state[:3]))
+                and last[3:] == state[3:]):
+            flags |= FLAG_REUSE_SORT
+        self._fused_token = state
         self._chk(self.lib.vps_deposit_fft_zy(self.ctx, self._ptr(pos), self._pos_kind(pos),
                                               self._ptr(vel, torch.float32), self._ptr(rho, torch.float32),
                                               pos.shape[0], N, float(Lbox), x0, nx, quantity, flags,
                                               self._ptr(spec), self._ptr(nyq), self._ptr(work)))
         return spec, nyq
+
+    def fused_token(self):
+        """Token of the last deposit_fft_zy call (pass it as reuse_sort= to the next one)."""
+        return getattr(self, "_fused_token", None)
 
     def nn_resample(self, pos, payload, axes, x0, nx, want_index=False, out=None):
         """Exact NN of every lattice point axes[0][x0:x0+nx] x axes[1] x axes[2]."""

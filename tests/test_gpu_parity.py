@@ -455,6 +455,31 @@ def test_particle_backed_boxfield_takes_the_fused_path_and_matches_the_grid_path
         assert np.allclose(fast.Psum, slow.Psum, rtol=2e-5, atol=0)
 
 
+def test_reuse_sort_is_safe_and_equal(K):
+    """Second quantity of the same particle tensors with the first call's token: same spectra as a fresh sort;
+    a stale token (other tensors, a modified tensor, another call in between) silently sorts again."""
+    from vpower import device
+    N, Np = 128, 300000
+    rng = np.random.default_rng(12)
+    mk = lambda: [K.to_device(rng.random((Np, 3)).astype(np.float32)), K.to_device(rng.standard_normal((Np, 3)).astype(np.float32)),
+                  K.to_device(np.exp(rng.standard_normal(Np)).astype(np.float32))]
+    a, b = mk(), mk()
+    ref_m = [t.clone() for t in K.deposit_fft_zy(a[0], a[1], a[2], N, 1.0, 0, N, device.MOMENTUM)]
+    ref_b = [t.clone() for t in K.deposit_fft_zy(b[0], b[1], b[2], N, 1.0, 0, N, device.MOMENTUM)]
+    K.deposit_fft_zy(a[0], a[1], a[2], N, 1.0, 0, N, device.VELOCITY)
+    tok = K.fused_token()
+    got = K.deposit_fft_zy(a[0], a[1], a[2], N, 1.0, 0, N, device.MOMENTUM, reuse_sort=tok)       # reused
+    assert all(float((g - r).abs().max()) <= 2e-5 * float(r.abs().max()) for g, r in zip(got, ref_m))
+    got = K.deposit_fft_zy(b[0], b[1], b[2], N, 1.0, 0, N, device.MOMENTUM, reuse_sort=tok)       # other tensors: re-sorted
+    assert all(float((g - r).abs().max()) <= 2e-5 * float(r.abs().max()) for g, r in zip(got, ref_b))
+    K.deposit_fft_zy(a[0], a[1], a[2], N, 1.0, 0, N, device.VELOCITY)
+    tok = K.fused_token()
+    a[0].mul_(0.5)                                                                                 # modified in place: re-sorted
+    got = K.deposit_fft_zy(a[0], a[1], a[2], N, 1.0, 0, N, device.MOMENTUM, reuse_sort=tok)
+    fresh = K.deposit_fft_zy(a[0].clone(), a[1], a[2], N, 1.0, 0, N, device.MOMENTUM)
+    assert all(float((g - r).abs().max()) <= 2e-5 * float(r.abs().max()) for g, r in zip(got, [t.clone() for t in fresh]))
+
+
 def test_fused_pipeline_against_oracle(K):
     from vpower import device
     N, L, Np = 64, 1.0, 60000
