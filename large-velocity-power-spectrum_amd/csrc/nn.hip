@@ -278,8 +278,10 @@ __global__ void __launch_bounds__(256)
     const int sx0 = __builtin_amdgcn_readfirstlane(max(wx0 - 1, 0)), sx1 = __builtin_amdgcn_readfirstlane(min(wx1 + 1, M - 1));
     const int sy0 = __builtin_amdgcn_readfirstlane(max(wy0 - 1, 0)), sy1 = __builtin_amdgcn_readfirstlane(min(wy1 + 1, M - 1));
     const int sz0 = __builtin_amdgcn_readfirstlane(max(wz0 - 1, 0)), sz1 = __builtin_amdgcn_readfirstlane(min(wz1 + 1, M - 1));
-    // pass 1, float32 only and branch-free: the smallest float32 squared distance
-    float best32 = INFINITY;
+    // pass 1, float32 only and branch-free: the TWO smallest float32 squared distances and where the
+    // smallest one sits in the staged records
+    float b1 = INFINITY, b2 = INFINITY;
+    int j1 = -1;
     for (int cx = sx0; cx <= sx1; ++cx)
       for (int cy = sy0; cy <= sy1; ++cy) {
         const int colrow = ((cx - cx0) * ncy + (cy - cy0)) * (ncz + 1) - cz0;
@@ -289,23 +291,32 @@ __global__ void __launch_bounds__(256)
           const float4 rec = lrec[j];
           const float fx = Qf[0] - rec.x, fy = Qf[1] - rec.y, fz = Qf[2] - rec.z;
           const float d2f = (fx * fx + fy * fy) + fz * fz;
-          best32 = d2f < best32 ? d2f : best32;   // (fminf's NaN rules cost a dozen instructions)
+          b2 = __builtin_amdgcn_fmed3f(b1, b2, d2f);   // b1 <= b2: the middle one is the new runner-up
+          j1 = d2f < b1 ? (int)j : j1;
+          b1 = d2f < b1 ? d2f : b1;                    // (fminf's NaN rules cost a dozen instructions)
         }
       }
-    // pass 2: the exact nearest particle p* satisfies d(p*) <= d(argmin32) <= sqrt(best32)+err,
-    // hence d32(p*) <= sqrt(best32) + 2 err: only those few candidates are re-evaluated in
-    // float64 (nn_consider screens against b.screen)
+    // The exact nearest particle p* satisfies d(p*) <= d(argmin32) <= sqrt(b1)+err, hence
+    // d32(p*) <= sqrt(b1) + 2 err =: screen.  When the runner-up lies beyond the screen the float32 winner is
+    // the exact one and a single float64 evaluation (for the termination test) finishes the lane; only if some
+    // lane of the wave has a contender inside its screen -- near ties, rare -- the wave makes a second sweep
+    // that re-evaluates those contenders in float64 (nn_consider screens against b.screen).
     {
-      const float rb = sqrtf(best32) * 1.000001f + 2.f * err;
+      const float rb = sqrtf(b1) * 1.000001f + 2.f * err;
       b.screen = rb * rb * 1.000001f;
     }
-    for (int cx = sx0; cx <= sx1; ++cx)
-      for (int cy = sy0; cy <= sy1; ++cy) {
-        const int colrow = ((cx - cx0) * ncy + (cy - cy0)) * (ncz + 1) - cz0;
-        const unsigned s = __builtin_amdgcn_readfirstlane(lstart[colrow + sz0]);
-        const unsigned e = __builtin_amdgcn_readfirstlane(lstart[colrow + sz1 + 1]);
-        for (unsigned j = s; j < e; ++j) nn_consider<F>(pos, lrec[j], Q, Qf, err, b);
-      }
+    const bool contested = valid && !(b2 > b.screen);
+    if (__any(contested)) {
+      for (int cx = sx0; cx <= sx1; ++cx)
+        for (int cy = sy0; cy <= sy1; ++cy) {
+          const int colrow = ((cx - cx0) * ncy + (cy - cy0)) * (ncz + 1) - cz0;
+          const unsigned s = __builtin_amdgcn_readfirstlane(lstart[colrow + sz0]);
+          const unsigned e = __builtin_amdgcn_readfirstlane(lstart[colrow + sz1 + 1]);
+          for (unsigned j = s; j < e; ++j) nn_consider<F>(pos, lrec[j], Q, Qf, err, b);
+        }
+    } else if (j1 >= 0) {
+      nn_consider<F>(pos, lrec[j1], Q, Qf, err, b);
+    }
     if (valid) {
       bool exhausted;
       finished = nn_done(g, c, Q, 1, b.best, exhausted);
