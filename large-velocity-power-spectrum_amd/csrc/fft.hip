@@ -125,6 +125,51 @@ struct Dft<16> {
   }
 };
 
+// radix 5 (forward, w = exp(-2 pi i/5)) and radix 10 = 2 x 5: lengths 2^a 5^b (N = 250, 500, 1000)
+#define VPS_C1_5 0.30901699437494742410f    /* cos(2 pi/5) */
+#define VPS_C2_5 (-0.80901699437494742410f) /* cos(4 pi/5) */
+#define VPS_S1_5 0.95105651629515357212f    /* sin(2 pi/5) */
+#define VPS_S2_5 0.58778525229247312917f    /* sin(4 pi/5) */
+template <>
+struct Dft<5> {
+  static __device__ __forceinline__ void run(cf* v) {
+    const cf a = cadd(v[1], v[4]), b = csub(v[1], v[4]);
+    const cf c = cadd(v[2], v[3]), d = csub(v[2], v[3]);
+    const cf t1 = make_float2(v[0].x + VPS_C1_5 * a.x + VPS_C2_5 * c.x, v[0].y + VPS_C1_5 * a.y + VPS_C2_5 * c.y);
+    const cf t2 = make_float2(v[0].x + VPS_C2_5 * a.x + VPS_C1_5 * c.x, v[0].y + VPS_C2_5 * a.y + VPS_C1_5 * c.y);
+    // u = -i * (s b +- s' d)
+    const cf q1 = make_float2(VPS_S1_5 * b.x + VPS_S2_5 * d.x, VPS_S1_5 * b.y + VPS_S2_5 * d.y);
+    const cf q2 = make_float2(VPS_S2_5 * b.x - VPS_S1_5 * d.x, VPS_S2_5 * b.y - VPS_S1_5 * d.y);
+    const cf u1 = cmul_mi(q1), u2 = cmul_mi(q2);
+    v[0] = make_float2(v[0].x + a.x + c.x, v[0].y + a.y + c.y);
+    v[1] = cadd(t1, u1);
+    v[4] = csub(t1, u1);
+    v[2] = cadd(t2, u2);
+    v[3] = csub(t2, u2);
+  }
+};
+template <>
+struct Dft<10> {
+  static __device__ __forceinline__ void run(cf* v) {
+    cf e[5] = {v[0], v[2], v[4], v[6], v[8]};
+    cf o[5] = {v[1], v[3], v[5], v[7], v[9]};
+    Dft<5>::run(e);
+    Dft<5>::run(o);
+    // o[k] *= w10^k, w10 = exp(-2 pi i/10): cos(pi/5) = -c2_5, sin(pi/5) = s2_5, cos(2pi/5) = c1_5, sin(2pi/5) = s1_5
+    const cf w1 = make_float2(-VPS_C2_5, -VPS_S2_5), w2 = make_float2(VPS_C1_5, -VPS_S1_5);
+    const cf w3 = make_float2(-VPS_C1_5, -VPS_S1_5), w4 = make_float2(VPS_C2_5, -VPS_S2_5);
+    o[1] = cmul(o[1], w1);
+    o[2] = cmul(o[2], w2);
+    o[3] = cmul(o[3], w3);
+    o[4] = cmul(o[4], w4);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      v[k] = cadd(e[k], o[k]);
+      v[k + 5] = csub(e[k], o[k]);
+    }
+  }
+};
+
 // ---- per-length plans: L lanes per line, radices R0*R1*R2 = NC -----------------
 template <int NC>
 struct Plan;
@@ -143,6 +188,11 @@ VPS_PLAN(512, 32, 8, 8, 8)
 VPS_PLAN(1024, 64, 16, 8, 8)
 VPS_PLAN(2048, 128, 16, 16, 8)
 VPS_PLAN(4096, 256, 16, 16, 16)
+// 2^a 5^b lengths: N = 250, 500, 1000 (lines of N/2 packed-real and N complex points)
+VPS_PLAN(125, 25, 5, 5, 5)
+VPS_PLAN(250, 25, 10, 5, 5)
+VPS_PLAN(500, 25, 10, 10, 5)
+VPS_PLAN(1000, 50, 10, 10, 10)
 
 template <int NC>
 struct PlanInfo {
@@ -200,7 +250,7 @@ __device__ __forceinline__ void twiddle_butterfly(cf (&v)[RL], const cf* tw, int
 #pragma unroll
   for (int m = 0; m < NB; ++m) {
     if constexpr (NS > 1) {
-      const int k = (l + L * m) & (NS - 1);
+      const int k = (l + L * m) % NS;   // (NS is a compile-time constant: a mask for powers of two)
 #pragma unroll
       for (int r = 1; r < R; ++r) v[m * R + r] = cmul(v[m * R + r], tw[(r - 1) * NS + k]);
     }
@@ -214,7 +264,7 @@ __device__ __forceinline__ void lds_store_stage(const cf (&v)[RL], cf* line, int
 #pragma unroll
   for (int m = 0; m < NB; ++m) {
     const int j = l + L * m;
-    const int k = j & (NS - 1);
+    const int k = j % NS;
     const int j0 = (j - k) * R + k;
 #pragma unroll
     for (int r = 0; r < R; ++r) line[padidx<NC>(j0 + r * NS)] = v[m * R + r];
@@ -304,7 +354,8 @@ __device__ __forceinline__ void store_stream(cf* ptr, cf v) {
 template <int NC, int T, int NT, bool BOUNDS>
 __device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf* __restrict__ tw_r2c, cf* out,
                                                long long out_ok, cf* nyq, int nlive) {
-  constexpr int PAIRS = (NC / 2) * T;
+  // pair index kp = 0 .. NC/2 (the last one only for odd NC: for even NC the self-paired mode NC/2 rides with kp = 0)
+  constexpr int PAIRS = (NC / 2 + (NC & 1)) * T;
   constexpr int IT = (PAIRS + NT - 1) / NT;
 #pragma unroll 4
   for (int i = 0; i < IT; ++i) {
@@ -314,11 +365,13 @@ __device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf*
     const bool ok = !BOUNDS || tt < nlive;
     const cf zk = buf[tridx<T>(k, tt)];
     if (k == 0) {
-      const cf zh = buf[tridx<T>(NC / 2, tt)];
       if (ok) {
         out[tt] = make_float2(zk.x + zk.y, 0.f);
         nyq[tt] = make_float2(zk.x - zk.y, 0.f);
-        out[(long long)(NC / 2) * out_ok + tt] = make_float2(zh.x, -zh.y);
+      }
+      if constexpr ((NC & 1) == 0) {
+        const cf zh = buf[tridx<T>(NC / 2, tt)];
+        if (ok) out[(long long)(NC / 2) * out_ok + tt] = make_float2(zh.x, -zh.y);
       }
     } else {
       const cf zn = buf[tridx<T>(NC - k, tt)];
@@ -806,7 +859,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
         // hoisted out of it as ~50 extra live registers (an occupancy step)
         int lc = l;
         asm volatile("" : "+v"(lc));
-        lc &= L - 1;   // give the value range back to the compiler (address folding needs it)
+        lc = (L & (L - 1)) == 0 ? (lc & (L - 1)) : lc % L;   // give the value range back to the compiler (address folding needs it)
         exchange_sync<WSYNC>();  // previous readers are done with the line buffers
         fft_from_regs<NC, WSYNC>(v, line, tw, lc);
 #pragma unroll
@@ -827,7 +880,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
       {
         int lw = l;   // opaque again: 16 store addresses recomputed per tile instead of kept live
         asm volatile("" : "+v"(lw));
-        lw &= L - 1;
+        lw = (L & (L - 1)) == 0 ? (lw & (L - 1)) : lw % L;
 #pragma unroll
         for (int i = 0; i < RL; ++i) {
           const int k = out_index<NC>(lw, i);
@@ -986,7 +1039,8 @@ constexpr int transpose_T() {
 template <int NC>
 constexpr int xpass_T() {
   constexpr int L = Plan<NC>::L;
-  return (256 / L) > 0 ? (256 / L) : 1;
+  constexpr int t = (256 / L) > 0 ? (256 / L) : 1;
+  return (t > 1 && (t & 1)) ? t - 1 : t;   // even, so that a tile holds whole (ky, N-ky) pairs (L = 50 -> 4)
 }
 
 template <int NC, int T>
@@ -1085,6 +1139,10 @@ int launch_x(vps_ctx* ctx, const XParams& p_in, bool fast = false) {
     case 1024: { constexpr int NC_ = 1024; CALL; } break;             \
     case 2048: { constexpr int NC_ = 2048; CALL; } break;             \
     case 4096: { constexpr int NC_ = 4096; CALL; } break;             \
+    case 125: { constexpr int NC_ = 125; CALL; } break;               \
+    case 250: { constexpr int NC_ = 250; CALL; } break;               \
+    case 500: { constexpr int NC_ = 500; CALL; } break;               \
+    case 1000: { constexpr int NC_ = 1000; CALL; } break;             \
     default: rc = vps_fail(ctx, VPS_ERR_UNSUPPORTED, "unsupported FFT length %d", (int)(NCVAL)); \
   }
 
@@ -1145,7 +1203,10 @@ void vps_fft_free_tables(vps_ctx* ctx) {
 
 extern "C" {
 
-int vps_fft_supported(int N) { return (N >= 16 && N <= 4096 && (N & (N - 1)) == 0) ? 1 : 0; }
+int vps_fft_supported(int N) {
+  if (N == 250 || N == 500 || N == 1000) return 1;   // 2^a 5^b plans (radix 5 / 10)
+  return (N >= 16 && N <= 4096 && (N & (N - 1)) == 0) ? 1 : 0;
+}
 
 size_t vps_fft_workspace_bytes(int N, int nx) {
   // B[x][kz][y] (kz < N/2) + Nyquist plane BN[x][y]
@@ -1160,7 +1221,7 @@ size_t vps_power_workspace_bytes(int N) {
 int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev, void* spec_dev, void* nyq_dev,
                void* work_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096]", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096] or 250, 500, 1000", N);
   if (nx < 1 || nx > N) return vps_fail(ctx, VPS_ERR_ARG, "nx=%d out of range", nx);
   if (!field_dev || !spec_dev || !nyq_dev || !work_dev) return vps_fail(ctx, VPS_ERR_ARG, "null buffer");
   const int NH = N / 2;
@@ -1318,7 +1379,7 @@ static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz
                       const void* in1_dev, const void* in2_dev, int ncomp, int nseg, int64_t seg_stride,
                       int mode, double* psum_dev, unsigned long long* nsample_dev, void* out_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096]", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096] or 250, 500, 1000", N);
   if (nlines < 0 || !in_dev) return vps_fail(ctx, VPS_ERR_ARG, "bad line count / null input");
   if (nseg < 1 || N % nseg) return vps_fail(ctx, VPS_ERR_ARG, "nseg=%d must divide N", nseg);
   if (nlines == 0) return VPS_OK;
@@ -1338,7 +1399,8 @@ static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz
   p.seglen = N / nseg;
   p.seg_shift = 0;
   while ((1 << p.seg_shift) < p.seglen) ++p.seg_shift;
-  if ((1 << p.seg_shift) != p.seglen) return vps_fail(ctx, VPS_ERR_ARG, "nseg=%d must be a power of two", nseg);
+  if (nseg > 1 && (1 << p.seg_shift) != p.seglen)
+    return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d in %d segments: segmented lines need a power-of-two segment length", N, nseg);
   p.seg_stride = seg_stride;
   p.tw_stage = tx.tw_stage;
   if (mode == 0 || mode == 3) {
@@ -1394,7 +1456,7 @@ int vps_fft_x_bin(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, c
 int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, double* psum_dev,
                   unsigned long long* nsample_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096]", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096] or 250, 500, 1000", N);
   const size_t half = vps_fft_workspace_bytes(N, N);
   char* w = reinterpret_cast<char*>(work_dev);
   cf* spec = reinterpret_cast<cf*>(w + half);
@@ -1408,7 +1470,7 @@ int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, d
 
 int vps_rfft3(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, void* out_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096]", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096] or 250, 500, 1000", N);
   const size_t half = vps_fft_workspace_bytes(N, N);
   char* w = reinterpret_cast<char*>(work_dev);
   cf* spec = reinterpret_cast<cf*>(w + half);
@@ -1423,7 +1485,7 @@ int vps_rfft3(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, void*
 
 int vps_power_grid(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, float* power_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096]", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096] or 250, 500, 1000", N);
   const size_t half = vps_fft_workspace_bytes(N, N);
   char* w = reinterpret_cast<char*>(work_dev);
   cf* spec = reinterpret_cast<cf*>(w + half);

@@ -183,7 +183,7 @@ def test_ann_interpolate_api():
 
 
 # ------------------------------------------------------------------ stage B ----
-@pytest.mark.parametrize("N", [16, 32, 64, 128, 256])
+@pytest.mark.parametrize("N", [16, 32, 64, 128, 256, 250])
 def test_rfft3_matches_numpy(K, N):
     rng = np.random.default_rng(N)
     f = rng.standard_normal((N, N, N)).astype(np.float32)
@@ -191,6 +191,34 @@ def test_rfft3_matches_numpy(K, N):
     ref = np.fft.rfftn(f.astype(np.float64)).transpose(2, 1, 0)     # [kz<=N/2, ky, kx]
     scale = np.sqrt(np.mean(np.abs(ref) ** 2))
     assert np.max(np.abs(got - ref)) / scale < FFT_RTOL
+
+
+def test_radix5_grid_sizes_against_the_oracle(K):
+    """N = 250 (the reference's own benchmark size, buffer_test.log): lines of 125 packed-real and 250 complex
+    points through the radix-5 / radix-10 plans -- NGP deposit on a non-power-of-two grid, spectrum with the
+    library binning: Nsample bit exact, Psum within the float32 bar.  N = 500 / 1000: plane-wave known answer."""
+    from vpower import device, interp
+    N, L, Np = 250, 1.0, 400000
+    pos, vel, mass, dens = synth(250, Np, L)
+    gp = interp.GasParticles(pos, mass, dens, vel, L)
+    sp = gp.deposit_to_field(N).spctrm("velocity")
+    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
+    v, m = orc.vm_from_vec_grid(orc.deposit_to_grid_fast(vec, pos, N, L), L / N, zero_empty=True)
+    ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, L / N, "velocity")
+    assert len(sp.k) == 125 and np.array_equal(sp.Nsample, ref[:, 3])
+    assert np.allclose(sp.Psum, ref[:, 2], rtol=PSUM_RTOL, atol=0)
+    for n, (a, b, c) in ((500, (3, 41, 7)), (1000, (11, 2, 333))):
+        x = np.arange(n, dtype=np.float64)
+        ph = 2 * np.pi * ((a * x)[:, None, None] + (b * x)[None, :, None] + (c * x)[None, None, :]) / n
+        f = K.to_device(np.cos(ph).astype(np.float32))
+        del ph
+        mag = K.rfft3(f, n).abs()
+        peak = float(mag[c, b, a])
+        assert abs(peak - n ** 3 / 2) < 2e-3 * n ** 3
+        mag[c, b, a] = 0
+        assert float(mag.max()) < 2e-4 * n ** 3
+        del f, mag
+        torch.cuda.empty_cache()
 
 
 def test_rfft3_plane_wave_known_answer(K):
@@ -517,7 +545,7 @@ def test_edge_cases_empty_single_and_errors(K):
     assert idx.shape == (5, 5, 5) and not idx.any()
     # unsupported sizes and bad arguments fail loudly, with the library's message
     with pytest.raises(Exception):
-        device.PowerPipeline(500, L, kernels=K, comm=device.SlabComm(enabled=False))
+        device.PowerPipeline(600, L, kernels=K, comm=device.SlabComm(enabled=False))
     with pytest.raises(_ffi.VpsError, match="slab"):
         K.deposit(K.zeros((4, 3), torch.float32), K.zeros((4, 1), torch.float32), N, L, 8, 16)
     with pytest.raises(_ffi.VpsError, match="contiguous|float32"):

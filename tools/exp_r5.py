@@ -1,0 +1,30 @@
+"""2^a 5^b grid sizes: device rfft3 and binned spectra against numpy / the oracle (GPU box)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "large-velocity-power-spectrum_amd"))
+import numpy as np, torch
+from vpower import device
+from oracle import vps_oracle as orc
+K = device.default_kernels()
+rng = np.random.default_rng(5)
+for N in [int(a) for a in sys.argv[1:]] or [250, 500]:
+    f = rng.standard_normal((N, N, N)).astype(np.float32)
+    F = K.rfft3(K.to_device(f), N).cpu().numpy()               # [kz<=N/2][ky][kx]
+    ref = np.fft.rfftn(f.astype(np.float64), axes=(0, 1, 2)).transpose(2, 1, 0)
+    err = np.abs(F - ref).max() / np.sqrt((np.abs(ref) ** 2).mean())
+    print("N=%d rfft3 max err / rms = %.2e" % (N, err), flush=True)
+    assert err < 5e-6
+    if N <= 250:
+        v = [rng.standard_normal((N, N, N)).astype(np.float32) for _ in range(3)]
+        pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=device.SlabComm(enabled=False))
+        tab = pipe.spectrum([K.to_device(a) for a in v])
+        m = np.ones((N, N, N))
+        ref = orc.box_spctrm(v[0].astype(np.float64), v[1].astype(np.float64), v[2].astype(np.float64), m, 1.0 / N, "velocity")
+        assert np.array_equal(tab[:, 3], ref[:, 3]), "Nsample differs"
+        rel = np.abs(tab[:, 2] - ref[:, 2]).max() / np.abs(ref[:, 2]).max()
+        print("N=%d spectrum: Nsample exact, Psum max rel %.2e, %d bins" % (N, rel, len(tab)), flush=True)
+        assert np.allclose(tab[:, 2], ref[:, 2], rtol=2e-5, atol=0)
+    fld = K.to_device(f)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): K.rfft3(fld, N)
+    torch.cuda.synchronize(); print("N=%d rfft3 %.3f ms" % (N, (time.perf_counter() - t0) / 5 * 1e3), flush=True)
