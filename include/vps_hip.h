@@ -168,8 +168,7 @@ int vps_field_algebra(vps_ctx* ctx, int quantity, int flags, double Lcell,
                       float* chans_dev, int64_t ncell);
 
 /* ---- stage B+C: 3-D R2C FFT, |f|^2, shell binning ------------------------ */
-/* Supported N: powers of two, 16 <= N <= 4096, and 250, 500, 1000 (radix-5 / 10 plans;
- * single-GPU layouts only: segmented lines need power-of-two segments).            */
+/* Supported N: powers of two, 16 <= N <= 4096, and 250, 500, 1000 (radix-5 / 10 plans). */
 int vps_fft_supported(int N);
 /* Binning tables (host pointers, copied):
  *   k2_axis[N]   = fl(k*k) for k = 2*pi*fftfreq(N, Lcell)   (interp.py:1449,1460)

@@ -691,7 +691,7 @@ struct XParams {
   cf* out;
   long long nlines, line0;
   int N, kz0;
-  int seglen, seg_shift;  // segment length (a power of two) and its log2
+  int seglen, seg_shift;  // segment length and its log2 (-1: not a power of two)
   long long seg_stride;
   const cf* tw_stage;
   const double* k2;
@@ -803,8 +803,11 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
           // element x of the line sits in segment x >> seg_shift at offset x & segmask
           // (this exact form -- a conditional double load, reinterpreted -- keeps every load a streaming one
           // with one base register and immediate offsets; going through load_stream() did not)
+          // (seg_shift < 0: segment length not a power of two -- the 2^a 5^b grids on several ranks)
+          const int sg = p.seg_shift >= 0 ? (x >> p.seg_shift) : x / p.seglen;
+          const int so = p.seg_shift >= 0 ? (x & segmask) : x - sg * p.seglen;
           const double raw = live ? __builtin_nontemporal_load(reinterpret_cast<const double*>(
-                                        &base[(long long)(x >> p.seg_shift) * p.seg_stride + (x & segmask)]))
+                                        &base[(long long)sg * p.seg_stride + so]))
                                   : 0.0;
           v[m * R + r] = *reinterpret_cast<const cf*>(&raw);
         } else {
@@ -1399,8 +1402,7 @@ static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz
   p.seglen = N / nseg;
   p.seg_shift = 0;
   while ((1 << p.seg_shift) < p.seglen) ++p.seg_shift;
-  if (nseg > 1 && (1 << p.seg_shift) != p.seglen)
-    return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d in %d segments: segmented lines need a power-of-two segment length", N, nseg);
+  if ((1 << p.seg_shift) != p.seglen) p.seg_shift = -1;   // not a power of two: the kernel divides
   p.seg_stride = seg_stride;
   p.tw_stage = tx.tw_stage;
   if (mode == 0 || mode == 3) {

@@ -497,9 +497,6 @@ class PowerPipeline:
         G = self.comm.world
         if not self.k.fft_supported(self.N):
             raise Exception("Nsize=%d is not supported by the device FFT (powers of two 16..4096, or 250, 500, 1000)" % self.N)
-        if G > 1 and self.N & (self.N - 1):
-            raise Exception("Nsize=%d: the slab decomposition over %d ranks needs a power-of-two grid "
-                            "(250, 500, 1000 run on one GPU)" % (self.N, G))
         if self.N % G or (self.N // 2) % G:
             raise Exception("Nsize/2=%d must be divisible by the number of ranks %d" % (self.N // 2, G))
         self.nx = self.N // G

@@ -571,7 +571,7 @@ def test_float64_positions_through_fused_deposit(K):
 
 
 # ------------------------------------------------ slab / segment layout, long lines ----
-@pytest.mark.parametrize("N,G", [(64, 2), (128, 4), (256, 8)])
+@pytest.mark.parametrize("N,G", [(64, 2), (128, 4), (256, 8), (250, 5), (500, 2)])
 def test_emulated_slab_ranks_on_one_gpu(K, N, G):
     """The multi-GPU data path with the real kernels: per-slab z/y passes, the all-to-all
     emulated by assembling each rank's receive buffer, segmented x pass with kz/ky offsets."""
