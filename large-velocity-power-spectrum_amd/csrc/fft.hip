@@ -125,6 +125,56 @@ struct Dft<16> {
   }
 };
 
+// radix 3, 6 = 2 x 3, 12 = 2 x 6 (forward): lengths 3 * 2^a (N = 96, 192, 384, 768)
+#define VPS_SQRT3_2 0.86602540378443864676f
+template <>
+struct Dft<3> {
+  static __device__ __forceinline__ void run(cf* v) {
+    const cf t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+    const cf m = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
+    const cf u = make_float2(VPS_SQRT3_2 * d.y, -VPS_SQRT3_2 * d.x);   // -i (sqrt(3)/2) d
+    v[0] = cadd(v[0], t);
+    v[1] = cadd(m, u);
+    v[2] = csub(m, u);
+  }
+};
+template <>
+struct Dft<6> {
+  static __device__ __forceinline__ void run(cf* v) {
+    cf e[3] = {v[0], v[2], v[4]};
+    cf o[3] = {v[1], v[3], v[5]};
+    Dft<3>::run(e);
+    Dft<3>::run(o);
+    o[1] = cmul(o[1], make_float2(0.5f, -VPS_SQRT3_2));    // w6
+    o[2] = cmul(o[2], make_float2(-0.5f, -VPS_SQRT3_2));   // w6^2
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      v[k] = cadd(e[k], o[k]);
+      v[k + 3] = csub(e[k], o[k]);
+    }
+  }
+};
+template <>
+struct Dft<12> {
+  static __device__ __forceinline__ void run(cf* v) {
+    cf e[6] = {v[0], v[2], v[4], v[6], v[8], v[10]};
+    cf o[6] = {v[1], v[3], v[5], v[7], v[9], v[11]};
+    Dft<6>::run(e);
+    Dft<6>::run(o);
+    // o[k] *= w12^k, w12 = exp(-i pi/6)
+    o[1] = cmul(o[1], make_float2(VPS_SQRT3_2, -0.5f));
+    o[2] = cmul(o[2], make_float2(0.5f, -VPS_SQRT3_2));
+    o[3] = cmul_mi(o[3]);
+    o[4] = cmul(o[4], make_float2(-0.5f, -VPS_SQRT3_2));
+    o[5] = cmul(o[5], make_float2(-VPS_SQRT3_2, -0.5f));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      v[k] = cadd(e[k], o[k]);
+      v[k + 6] = csub(e[k], o[k]);
+    }
+  }
+};
+
 // radix 5 (forward, w = exp(-2 pi i/5)) and radix 10 = 2 x 5: lengths 2^a 5^b (N = 250, 500, 1000)
 #define VPS_C1_5 0.30901699437494742410f    /* cos(2 pi/5) */
 #define VPS_C2_5 (-0.80901699437494742410f) /* cos(4 pi/5) */
@@ -189,6 +239,12 @@ VPS_PLAN(1024, 64, 16, 8, 8)
 VPS_PLAN(2048, 128, 16, 16, 8)
 VPS_PLAN(4096, 256, 16, 16, 16)
 // 2^a 5^b lengths: N = 250, 500, 1000 (lines of N/2 packed-real and N complex points)
+// 3 * 2^a lengths: N = 96, 192, 384, 768
+VPS_PLAN(48, 2, 8, 6, 1)
+VPS_PLAN(96, 4, 8, 12, 1)
+VPS_PLAN(192, 8, 8, 8, 3)
+VPS_PLAN(384, 16, 8, 8, 6)
+VPS_PLAN(768, 32, 8, 8, 12)
 VPS_PLAN(125, 25, 5, 5, 5)
 VPS_PLAN(250, 25, 10, 5, 5)
 VPS_PLAN(500, 25, 10, 10, 5)
@@ -1142,6 +1198,11 @@ int launch_x(vps_ctx* ctx, const XParams& p_in, bool fast = false) {
     case 1024: { constexpr int NC_ = 1024; CALL; } break;             \
     case 2048: { constexpr int NC_ = 2048; CALL; } break;             \
     case 4096: { constexpr int NC_ = 4096; CALL; } break;             \
+    case 48: { constexpr int NC_ = 48; CALL; } break;                 \
+    case 96: { constexpr int NC_ = 96; CALL; } break;                 \
+    case 192: { constexpr int NC_ = 192; CALL; } break;               \
+    case 384: { constexpr int NC_ = 384; CALL; } break;               \
+    case 768: { constexpr int NC_ = 768; CALL; } break;               \
     case 125: { constexpr int NC_ = 125; CALL; } break;               \
     case 250: { constexpr int NC_ = 250; CALL; } break;               \
     case 500: { constexpr int NC_ = 500; CALL; } break;               \
@@ -1208,6 +1269,7 @@ extern "C" {
 
 int vps_fft_supported(int N) {
   if (N == 250 || N == 500 || N == 1000) return 1;   // 2^a 5^b plans (radix 5 / 10)
+  if (N == 96 || N == 192 || N == 384 || N == 768) return 1;   // 3 * 2^a plans (radix 3 / 6 / 12)
   return (N >= 16 && N <= 4096 && (N & (N - 1)) == 0) ? 1 : 0;
 }
 
@@ -1224,7 +1286,7 @@ size_t vps_power_workspace_bytes(int N) {
 int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev, void* spec_dev, void* nyq_dev,
                void* work_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096] or 250, 500, 1000", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 250, 500 or 1000", N);
   if (nx < 1 || nx > N) return vps_fail(ctx, VPS_ERR_ARG, "nx=%d out of range", nx);
   if (!field_dev || !spec_dev || !nyq_dev || !work_dev) return vps_fail(ctx, VPS_ERR_ARG, "null buffer");
   const int NH = N / 2;
@@ -1323,6 +1385,9 @@ bool vps_pencil_supported(vps_ctx* ctx, int N) {
     case 256: lds = pencil_lds_bytes<256>(); break;
     case 512: lds = pencil_lds_bytes<512>(); break;
     case 1024: lds = pencil_lds_bytes<1024>(); break;
+    case 96: lds = pencil_lds_bytes<96>(); break;
+    case 192: lds = pencil_lds_bytes<192>(); break;
+    case 384: lds = pencil_lds_bytes<384>(); break;
     default: return false;
   }
   return lds <= ctx->lds_per_cu;
@@ -1363,6 +1428,9 @@ int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, cons
     case 256: rc = launch_pencil<256>(ctx, p, npencils); break;
     case 512: rc = launch_pencil<512>(ctx, p, npencils); break;
     case 1024: rc = launch_pencil<1024>(ctx, p, npencils); break;
+    case 96: rc = launch_pencil<96>(ctx, p, npencils); break;
+    case 192: rc = launch_pencil<192>(ctx, p, npencils); break;
+    case 384: rc = launch_pencil<384>(ctx, p, npencils); break;
     default: rc = vps_fail(ctx, VPS_ERR_UNSUPPORTED, "pencil path: N=%d", N);
   }
   if (rc) return rc;
@@ -1382,7 +1450,7 @@ static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz
                       const void* in1_dev, const void* in2_dev, int ncomp, int nseg, int64_t seg_stride,
                       int mode, double* psum_dev, unsigned long long* nsample_dev, void* out_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096] or 250, 500, 1000", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 250, 500 or 1000", N);
   if (nlines < 0 || !in_dev) return vps_fail(ctx, VPS_ERR_ARG, "bad line count / null input");
   if (nseg < 1 || N % nseg) return vps_fail(ctx, VPS_ERR_ARG, "nseg=%d must divide N", nseg);
   if (nlines == 0) return VPS_OK;
@@ -1458,7 +1526,7 @@ int vps_fft_x_bin(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, c
 int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, double* psum_dev,
                   unsigned long long* nsample_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096] or 250, 500, 1000", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 250, 500 or 1000", N);
   const size_t half = vps_fft_workspace_bytes(N, N);
   char* w = reinterpret_cast<char*>(work_dev);
   cf* spec = reinterpret_cast<cf*>(w + half);
@@ -1472,7 +1540,7 @@ int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, d
 
 int vps_rfft3(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, void* out_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096] or 250, 500, 1000", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 250, 500 or 1000", N);
   const size_t half = vps_fft_workspace_bytes(N, N);
   char* w = reinterpret_cast<char*>(work_dev);
   cf* spec = reinterpret_cast<cf*>(w + half);
@@ -1487,7 +1555,7 @@ int vps_rfft3(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, void*
 
 int vps_power_grid(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, float* power_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096] or 250, 500, 1000", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 250, 500 or 1000", N);
   const size_t half = vps_fft_workspace_bytes(N, N);
   char* w = reinterpret_cast<char*>(work_dev);
   cf* spec = reinterpret_cast<cf*>(w + half);

@@ -183,7 +183,7 @@ def test_ann_interpolate_api():
 
 
 # ------------------------------------------------------------------ stage B ----
-@pytest.mark.parametrize("N", [16, 32, 64, 128, 256, 250])
+@pytest.mark.parametrize("N", [16, 32, 64, 128, 256, 250, 96, 192])
 def test_rfft3_matches_numpy(K, N):
     rng = np.random.default_rng(N)
     f = rng.standard_normal((N, N, N)).astype(np.float32)
@@ -196,7 +196,8 @@ def test_rfft3_matches_numpy(K, N):
 def test_radix5_grid_sizes_against_the_oracle(K):
     """N = 250 (the reference's own benchmark size, buffer_test.log): lines of 125 packed-real and 250 complex
     points through the radix-5 / radix-10 plans -- NGP deposit on a non-power-of-two grid, spectrum with the
-    library binning: Nsample bit exact, Psum within the float32 bar.  N = 500 / 1000: plane-wave known answer."""
+    library binning: Nsample bit exact, Psum within the float32 bar.  N = 500 / 1000 and the 3 * 2^a sizes 384 / 768
+    (radix 3 / 6 / 12): plane-wave known answer."""
     from vpower import device, interp
     N, L, Np = 250, 1.0, 400000
     pos, vel, mass, dens = synth(250, Np, L)
@@ -207,7 +208,7 @@ def test_radix5_grid_sizes_against_the_oracle(K):
     ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, L / N, "velocity")
     assert len(sp.k) == 125 and np.array_equal(sp.Nsample, ref[:, 3])
     assert np.allclose(sp.Psum, ref[:, 2], rtol=PSUM_RTOL, atol=0)
-    for n, (a, b, c) in ((500, (3, 41, 7)), (1000, (11, 2, 333))):
+    for n, (a, b, c) in ((500, (3, 41, 7)), (1000, (11, 2, 333)), (384, (5, 150, 9)), (768, (300, 1, 77))):
         x = np.arange(n, dtype=np.float64)
         ph = 2 * np.pi * ((a * x)[:, None, None] + (b * x)[None, :, None] + (c * x)[None, None, :]) / n
         f = K.to_device(np.cos(ph).astype(np.float32))
@@ -406,7 +407,7 @@ def test_config1_full_size_against_oracle():
 
 # ------------------------------------------------ fused deposit -> z pass (pencils) ----
 @pytest.mark.parametrize("N,nx,x0", [(64, 64, 0), (128, 128, 0), (128, 32, 64), (256, 256, 0), (512, 64, 448), (1024, 16, 480),
-                                     (2048, 4, 1000)])
+                                     (2048, 4, 1000), (192, 192, 0), (384, 48, 96), (768, 16, 752)])
 @pytest.mark.parametrize("quantity,flags", [("velocity", 0), ("momentum", 0), ("momentum", 1)])
 def test_fused_deposit_fft_matches_unfused(K, N, nx, x0, quantity, flags):
     from vpower import device
