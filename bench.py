@@ -63,6 +63,14 @@ def cpu_baseline(sample_N=256, density=10_000_000 / 512 ** 3):
     }
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim (the file travels with the repo)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "particles gridded/s + 3D FFT cells/s (Ngrid\u00b3) at 1/2/4/8 GPUs; HBM % of roofline"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,8 +218,9 @@ def main():
             traffic = None
 
     out = {
-        "metric": "particles gridded/s + 3D FFT cells/s (N^3 x components / step time, whole path "
-                  "particles->P(k)); HBM % of roofline",
+        "metric": baseline_metric(),
+        "value_definition": "N^3 x components / step time: the whole path particles -> P(k) table; stage rates in "
+                            "particles_per_s and fft_cells_per_s, HBM fraction in roofline",
         "value": cells * args.steps / dt,
         "unit": "grid cells*components/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
