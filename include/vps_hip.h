@@ -168,8 +168,8 @@ int vps_field_algebra(vps_ctx* ctx, int quantity, int flags, double Lcell,
                       float* chans_dev, int64_t ncell);
 
 /* ---- stage B+C: 3-D R2C FFT, |f|^2, shell binning ------------------------ */
-/* Supported N: powers of two, 16 <= N <= 4096; 96, 192, 384, 768 (radix-3 / 6 / 12 plans);
- * 250, 500, 1000 (radix-5 / 10 plans).                                             */
+/* Supported N: powers of two, 16 <= N <= 4096; 96, 192, 384, 768, 1536 (radix 3 / 6 / 12 / 24);
+ * 250, 500, 1000, 2000 (radix 5 / 10 / 20).                                          */
 int vps_fft_supported(int N);
 /* Binning tables (host pointers, copied):
  *   k2_axis[N]   = fl(k*k) for k = 2*pi*fftfreq(N, Lcell)   (interp.py:1449,1460)

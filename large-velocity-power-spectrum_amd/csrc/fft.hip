@@ -220,6 +220,84 @@ struct Dft<10> {
   }
 };
 
+// radix 24 = 8 x 3 and radix 20 = 5 x 4 (generated: twiddle constants are cos / sin of -2 pi m / N in double, printed to 17 digits)
+template <>
+struct Dft<24> {
+  static __device__ __forceinline__ void run(cf* v) {
+    // n = 3 n1 + n2, k = k1 + 8 k2: 3 x Dft<8>, twiddles w24^(n2 k1), 8 x Dft<3>
+    cf y[3][8];
+#pragma unroll
+    for (int n2 = 0; n2 < 3; ++n2) {
+      cf t[8];
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1) t[n1] = v[3 * n1 + n2];
+      Dft<8>::run(t);
+#pragma unroll
+      for (int k1 = 0; k1 < 8; ++k1) y[n2][k1] = t[k1];
+    }
+    y[1][1] = cmul(y[1][1], make_float2(0.96592582628906831f, -0.25881904510252074f));
+    y[1][2] = cmul(y[1][2], make_float2(0.86602540378443871f, -0.49999999999999994f));
+    y[1][3] = cmul(y[1][3], make_float2(0.70710678118654757f, -0.70710678118654746f));
+    y[1][4] = cmul(y[1][4], make_float2(0.50000000000000011f, -0.8660254037844386f));
+    y[1][5] = cmul(y[1][5], make_float2(0.25881904510252074f, -0.96592582628906831f));
+    y[1][6] = cmul_mi(y[1][6]);
+    y[1][7] = cmul(y[1][7], make_float2(-0.25881904510252063f, -0.96592582628906831f));
+    y[2][1] = cmul(y[2][1], make_float2(0.86602540378443871f, -0.49999999999999994f));
+    y[2][2] = cmul(y[2][2], make_float2(0.50000000000000011f, -0.8660254037844386f));
+    y[2][3] = cmul_mi(y[2][3]);
+    y[2][4] = cmul(y[2][4], make_float2(-0.49999999999999978f, -0.86602540378443871f));
+    y[2][5] = cmul(y[2][5], make_float2(-0.86602540378443871f, -0.49999999999999994f));
+    y[2][6] = make_float2(-y[2][6].x, -y[2][6].y);
+    y[2][7] = cmul(y[2][7], make_float2(-0.86602540378443882f, 0.49999999999999972f));
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+      cf t[3];
+#pragma unroll
+      for (int n2 = 0; n2 < 3; ++n2) t[n2] = y[n2][k1];
+      Dft<3>::run(t);
+#pragma unroll
+      for (int k2 = 0; k2 < 3; ++k2) v[k1 + 8 * k2] = t[k2];
+    }
+  }
+};
+template <>
+struct Dft<20> {
+  static __device__ __forceinline__ void run(cf* v) {
+    // n = 4 n1 + n2, k = k1 + 5 k2: 4 x Dft<5>, twiddles w20^(n2 k1), 5 x Dft<4>
+    cf y[4][5];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) {
+      cf t[5];
+#pragma unroll
+      for (int n1 = 0; n1 < 5; ++n1) t[n1] = v[4 * n1 + n2];
+      Dft<5>::run(t);
+#pragma unroll
+      for (int k1 = 0; k1 < 5; ++k1) y[n2][k1] = t[k1];
+    }
+    y[1][1] = cmul(y[1][1], make_float2(0.95105651629515353f, -0.3090169943749474f));
+    y[1][2] = cmul(y[1][2], make_float2(0.80901699437494745f, -0.58778525229247314f));
+    y[1][3] = cmul(y[1][3], make_float2(0.58778525229247314f, -0.80901699437494745f));
+    y[1][4] = cmul(y[1][4], make_float2(0.30901699437494745f, -0.95105651629515353f));
+    y[2][1] = cmul(y[2][1], make_float2(0.80901699437494745f, -0.58778525229247314f));
+    y[2][2] = cmul(y[2][2], make_float2(0.30901699437494745f, -0.95105651629515353f));
+    y[2][3] = cmul(y[2][3], make_float2(-0.30901699437494734f, -0.95105651629515364f));
+    y[2][4] = cmul(y[2][4], make_float2(-0.80901699437494734f, -0.58778525229247325f));
+    y[3][1] = cmul(y[3][1], make_float2(0.58778525229247314f, -0.80901699437494745f));
+    y[3][2] = cmul(y[3][2], make_float2(-0.30901699437494734f, -0.95105651629515364f));
+    y[3][3] = cmul(y[3][3], make_float2(-0.95105651629515353f, -0.30901699437494751f));
+    y[3][4] = cmul(y[3][4], make_float2(-0.80901699437494756f, 0.58778525229247303f));
+#pragma unroll
+    for (int k1 = 0; k1 < 5; ++k1) {
+      cf t[4];
+#pragma unroll
+      for (int n2 = 0; n2 < 4; ++n2) t[n2] = y[n2][k1];
+      Dft<4>::run(t);
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) v[k1 + 5 * k2] = t[k2];
+    }
+  }
+};
+
 // ---- per-length plans: L lanes per line, radices R0*R1*R2 = NC -----------------
 template <int NC>
 struct Plan;
@@ -245,10 +323,12 @@ VPS_PLAN(96, 4, 8, 12, 1)
 VPS_PLAN(192, 8, 8, 8, 3)
 VPS_PLAN(384, 16, 8, 8, 6)
 VPS_PLAN(768, 32, 8, 8, 12)
+VPS_PLAN(1536, 64, 8, 8, 24)
 VPS_PLAN(125, 25, 5, 5, 5)
 VPS_PLAN(250, 25, 10, 5, 5)
 VPS_PLAN(500, 25, 10, 10, 5)
 VPS_PLAN(1000, 50, 10, 10, 10)
+VPS_PLAN(2000, 100, 10, 10, 20)
 
 template <int NC>
 struct PlanInfo {
@@ -1203,6 +1283,8 @@ int launch_x(vps_ctx* ctx, const XParams& p_in, bool fast = false) {
     case 192: { constexpr int NC_ = 192; CALL; } break;               \
     case 384: { constexpr int NC_ = 384; CALL; } break;               \
     case 768: { constexpr int NC_ = 768; CALL; } break;               \
+    case 1536: { constexpr int NC_ = 1536; CALL; } break;             \
+    case 2000: { constexpr int NC_ = 2000; CALL; } break;             \
     case 125: { constexpr int NC_ = 125; CALL; } break;               \
     case 250: { constexpr int NC_ = 250; CALL; } break;               \
     case 500: { constexpr int NC_ = 500; CALL; } break;               \
@@ -1268,8 +1350,8 @@ void vps_fft_free_tables(vps_ctx* ctx) {
 extern "C" {
 
 int vps_fft_supported(int N) {
-  if (N == 250 || N == 500 || N == 1000) return 1;   // 2^a 5^b plans (radix 5 / 10)
-  if (N == 96 || N == 192 || N == 384 || N == 768) return 1;   // 3 * 2^a plans (radix 3 / 6 / 12)
+  if (N == 250 || N == 500 || N == 1000 || N == 2000) return 1;   // 2^a 5^b plans (radix 5 / 10 / 20)
+  if (N == 96 || N == 192 || N == 384 || N == 768 || N == 1536) return 1;   // 3 * 2^a plans (radix 3 / 6 / 12 / 24)
   return (N >= 16 && N <= 4096 && (N & (N - 1)) == 0) ? 1 : 0;
 }
 
@@ -1286,7 +1368,7 @@ size_t vps_power_workspace_bytes(int N) {
 int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev, void* spec_dev, void* nyq_dev,
                void* work_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 250, 500 or 1000", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   if (nx < 1 || nx > N) return vps_fail(ctx, VPS_ERR_ARG, "nx=%d out of range", nx);
   if (!field_dev || !spec_dev || !nyq_dev || !work_dev) return vps_fail(ctx, VPS_ERR_ARG, "null buffer");
   const int NH = N / 2;
@@ -1388,6 +1470,7 @@ bool vps_pencil_supported(vps_ctx* ctx, int N) {
     case 96: lds = pencil_lds_bytes<96>(); break;
     case 192: lds = pencil_lds_bytes<192>(); break;
     case 384: lds = pencil_lds_bytes<384>(); break;
+    case 768: lds = pencil_lds_bytes<768>(); break;
     default: return false;
   }
   return lds <= ctx->lds_per_cu;
@@ -1431,6 +1514,7 @@ int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, cons
     case 96: rc = launch_pencil<96>(ctx, p, npencils); break;
     case 192: rc = launch_pencil<192>(ctx, p, npencils); break;
     case 384: rc = launch_pencil<384>(ctx, p, npencils); break;
+    case 768: rc = launch_pencil<768>(ctx, p, npencils); break;
     default: rc = vps_fail(ctx, VPS_ERR_UNSUPPORTED, "pencil path: N=%d", N);
   }
   if (rc) return rc;
@@ -1450,7 +1534,7 @@ static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz
                       const void* in1_dev, const void* in2_dev, int ncomp, int nseg, int64_t seg_stride,
                       int mode, double* psum_dev, unsigned long long* nsample_dev, void* out_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 250, 500 or 1000", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   if (nlines < 0 || !in_dev) return vps_fail(ctx, VPS_ERR_ARG, "bad line count / null input");
   if (nseg < 1 || N % nseg) return vps_fail(ctx, VPS_ERR_ARG, "nseg=%d must divide N", nseg);
   if (nlines == 0) return VPS_OK;
@@ -1526,7 +1610,7 @@ int vps_fft_x_bin(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, c
 int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, double* psum_dev,
                   unsigned long long* nsample_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 250, 500 or 1000", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   const size_t half = vps_fft_workspace_bytes(N, N);
   char* w = reinterpret_cast<char*>(work_dev);
   cf* spec = reinterpret_cast<cf*>(w + half);
@@ -1540,7 +1624,7 @@ int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, d
 
 int vps_rfft3(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, void* out_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 250, 500 or 1000", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   const size_t half = vps_fft_workspace_bytes(N, N);
   char* w = reinterpret_cast<char*>(work_dev);
   cf* spec = reinterpret_cast<cf*>(w + half);
@@ -1555,7 +1639,7 @@ int vps_rfft3(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, void*
 
 int vps_power_grid(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, float* power_dev) {
   if (!ctx) return VPS_ERR_ARG;
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 250, 500 or 1000", N);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   const size_t half = vps_fft_workspace_bytes(N, N);
   char* w = reinterpret_cast<char*>(work_dev);
   cf* spec = reinterpret_cast<cf*>(w + half);

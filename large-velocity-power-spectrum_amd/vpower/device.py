@@ -496,7 +496,7 @@ class PowerPipeline:
         self.comm = comm if comm is not None else SlabComm()
         G = self.comm.world
         if not self.k.fft_supported(self.N):
-            raise Exception("Nsize=%d is not supported by the device FFT (powers of two 16..4096, 96, 192, 384, 768, 250, 500, 1000)" % self.N)
+            raise Exception("Nsize=%d is not supported by the device FFT (powers of two 16..4096, 96, 192, 384, 768, 1536, 250, 500, 1000, 2000)" % self.N)
         if self.N % G or (self.N // 2) % G:
             raise Exception("Nsize/2=%d must be divisible by the number of ranks %d" % (self.N // 2, G))
         self.nx = self.N // G

@@ -407,7 +407,7 @@ def test_config1_full_size_against_oracle():
 
 # ------------------------------------------------ fused deposit -> z pass (pencils) ----
 @pytest.mark.parametrize("N,nx,x0", [(64, 64, 0), (128, 128, 0), (128, 32, 64), (256, 256, 0), (512, 64, 448), (1024, 16, 480),
-                                     (2048, 4, 1000), (192, 192, 0), (384, 48, 96), (768, 16, 752)])
+                                     (2048, 4, 1000), (192, 192, 0), (384, 48, 96), (768, 16, 752), (1536, 8, 8)])
 @pytest.mark.parametrize("quantity,flags", [("velocity", 0), ("momentum", 0), ("momentum", 1)])
 def test_fused_deposit_fft_matches_unfused(K, N, nx, x0, quantity, flags):
     from vpower import device
@@ -610,9 +610,9 @@ def _plane_waves(N, modes, x0, nx, device):
     return f
 
 
-@pytest.mark.parametrize("N,G", [(1024, 1), (1024, 4), (2048, 8)])
+@pytest.mark.parametrize("N,G", [(1024, 1), (1024, 4), (2048, 8), (1536, 8), (2000, 8)])
 def test_large_grid_plane_wave_known_answer(K, N, G):
-    """Long-line kernels (N = 1024, 2048) through the slab layout: a few plane waves must land
+    """Long-line kernels (N = 1024, 2048; 1536 = 8*8*24 and 2000 = 10*10*20) through the slab layout: a few plane waves must land
     in exactly their shells with power 2 (A N^3 / 2)^2, everything else ~ 0."""
     from vpower import device
     modes = [((3, 5, 7), 1.0), ((N // 2 - 1, 11, 2), 0.5), ((17, N - 9, N // 4), 2.0), ((0, 0, 40), 1.5)]
