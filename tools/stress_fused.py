@@ -8,7 +8,9 @@ K = device.default_kernels()
 rng = np.random.default_rng(2024)
 cases = [(64, 64, 0, 3000, "uniform"), (256, 64, 128, 2_000_000, "clump"), (512, 512, 0, 20_000_000, "uniform"),
          (512, 16, 496, 5_000_000, "clump"), (1024, 64, 512, 30_000_000, "uniform"), (2048, 16, 64, 20_000_000, "sheet"),
-         (128, 128, 0, 5_000_000, "onecell"), (512, 32, 0, 1000, "outside")]
+         (128, 128, 0, 5_000_000, "onecell"), (512, 32, 0, 1000, "outside"),
+         (192, 192, 0, 2_000_000, "clump"), (384, 96, 288, 3_000_000, "uniform"), (768, 32, 100, 5_000_000, "clump"),
+         (1536, 16, 64, 20_000_000, "sheet")]
 worst = 0.0
 for N, nx, x0, Np, kind in cases:
     pos = rng.random((Np, 3)).astype(np.float32)
