@@ -1266,31 +1266,54 @@ int launch_x(vps_ctx* ctx, const XParams& p_in, bool fast = false) {
   return VPS_OK;
 }
 
+// ---- translation-unit split ---------------------------------------------------------------
+// Every line length instantiates ~20 kernels, and 21 lengths in one translation unit take minutes to
+// compile.  The build therefore compiles this file once per length FAMILY (-DVPS_FFT_PART=0..3): each
+// part instantiates the launchers of its own lengths behind the five vps_fftpart_* entry points below,
+// and part 0 also holds the API, the tables and the routing.  Without the macro (VPS_FFT_PART = -1:
+// tools/build_variant.sh, single-file builds) one unit holds everything.
+#ifndef VPS_FFT_PART
+#define VPS_FFT_PART -1
+#endif
+#define VPS_PART_NOT_MINE (-12345)
+#define VPS_CAT2(a, b) a##b
+#define VPS_CAT(a, b) VPS_CAT2(a, b)
+#if VPS_FFT_PART == -1
+#define VPS_PARTFN(name) VPS_CAT(name, _all)
+#else
+#define VPS_PARTFN(name) VPS_CAT(VPS_CAT(name, _p), VPS_FFT_PART)
+#endif
+
+#if VPS_FFT_PART == -1 || VPS_FFT_PART == 0
+#define VPS_FAMILY_0(CALL) case 8: { constexpr int NC_ = 8; CALL; } break; case 16: { constexpr int NC_ = 16; CALL; } break; case 32: { constexpr int NC_ = 32; CALL; } break; case 64: { constexpr int NC_ = 64; CALL; } break; case 128: { constexpr int NC_ = 128; CALL; } break; case 256: { constexpr int NC_ = 256; CALL; } break;
+#else
+#define VPS_FAMILY_0(CALL)
+#endif
+#if VPS_FFT_PART == -1 || VPS_FFT_PART == 1
+#define VPS_FAMILY_1(CALL) case 512: { constexpr int NC_ = 512; CALL; } break; case 1024: { constexpr int NC_ = 1024; CALL; } break; case 2048: { constexpr int NC_ = 2048; CALL; } break; case 4096: { constexpr int NC_ = 4096; CALL; } break;
+#else
+#define VPS_FAMILY_1(CALL)
+#endif
+#if VPS_FFT_PART == -1 || VPS_FFT_PART == 2
+#define VPS_FAMILY_2(CALL) case 48: { constexpr int NC_ = 48; CALL; } break; case 96: { constexpr int NC_ = 96; CALL; } break; case 192: { constexpr int NC_ = 192; CALL; } break; case 384: { constexpr int NC_ = 384; CALL; } break; case 768: { constexpr int NC_ = 768; CALL; } break; case 1536: { constexpr int NC_ = 1536; CALL; } break;
+#else
+#define VPS_FAMILY_2(CALL)
+#endif
+#if VPS_FFT_PART == -1 || VPS_FFT_PART == 3
+#define VPS_FAMILY_3(CALL) case 125: { constexpr int NC_ = 125; CALL; } break; case 250: { constexpr int NC_ = 250; CALL; } break; case 500: { constexpr int NC_ = 500; CALL; } break; case 1000: { constexpr int NC_ = 1000; CALL; } break; case 2000: { constexpr int NC_ = 2000; CALL; } break;
+#else
+#define VPS_FAMILY_3(CALL)
+#endif
+
 #define VPS_DISPATCH_NC(NCVAL, CALL)                                  \
   switch (NCVAL) {                                                    \
-    case 8: { constexpr int NC_ = 8; CALL; } break;                   \
-    case 16: { constexpr int NC_ = 16; CALL; } break;                 \
-    case 32: { constexpr int NC_ = 32; CALL; } break;                 \
-    case 64: { constexpr int NC_ = 64; CALL; } break;                 \
-    case 128: { constexpr int NC_ = 128; CALL; } break;               \
-    case 256: { constexpr int NC_ = 256; CALL; } break;               \
-    case 512: { constexpr int NC_ = 512; CALL; } break;               \
-    case 1024: { constexpr int NC_ = 1024; CALL; } break;             \
-    case 2048: { constexpr int NC_ = 2048; CALL; } break;             \
-    case 4096: { constexpr int NC_ = 4096; CALL; } break;             \
-    case 48: { constexpr int NC_ = 48; CALL; } break;                 \
-    case 96: { constexpr int NC_ = 96; CALL; } break;                 \
-    case 192: { constexpr int NC_ = 192; CALL; } break;               \
-    case 384: { constexpr int NC_ = 384; CALL; } break;               \
-    case 768: { constexpr int NC_ = 768; CALL; } break;               \
-    case 1536: { constexpr int NC_ = 1536; CALL; } break;             \
-    case 2000: { constexpr int NC_ = 2000; CALL; } break;             \
-    case 125: { constexpr int NC_ = 125; CALL; } break;               \
-    case 250: { constexpr int NC_ = 250; CALL; } break;               \
-    case 500: { constexpr int NC_ = 500; CALL; } break;               \
-    case 1000: { constexpr int NC_ = 1000; CALL; } break;             \
-    default: rc = vps_fail(ctx, VPS_ERR_UNSUPPORTED, "unsupported FFT length %d", (int)(NCVAL)); \
+    VPS_FAMILY_0(CALL)                                               \
+    VPS_FAMILY_1(CALL)                                               \
+    VPS_FAMILY_2(CALL)                                               \
+    VPS_FAMILY_3(CALL)                                               \
+    default: rc = VPS_PART_NOT_MINE;                                   \
   }
+
 
 // host-side twiddle image for complex length NC (double precision, rounded once)
 template <int NC>
@@ -1314,6 +1337,128 @@ void build_stage_tw(std::vector<cf>& out) {
 
 }  // namespace
 
+// ---- per-part entry points (this unit's line lengths; VPS_PART_NOT_MINE for the others) ----
+#if VPS_FFT_PART == -1 || VPS_FFT_PART == 0
+#define VPS_PENCIL_FAMILY_0(CALL) case 32: { constexpr int NC_ = 32; CALL; } break; case 64: { constexpr int NC_ = 64; CALL; } break; case 128: { constexpr int NC_ = 128; CALL; } break; case 256: { constexpr int NC_ = 256; CALL; } break;
+#else
+#define VPS_PENCIL_FAMILY_0(CALL)
+#endif
+#if VPS_FFT_PART == -1 || VPS_FFT_PART == 1
+#define VPS_PENCIL_FAMILY_1(CALL) case 512: { constexpr int NC_ = 512; CALL; } break; case 1024: { constexpr int NC_ = 1024; CALL; } break;
+#else
+#define VPS_PENCIL_FAMILY_1(CALL)
+#endif
+#if VPS_FFT_PART == -1 || VPS_FFT_PART == 2
+#define VPS_PENCIL_FAMILY_2(CALL) case 96: { constexpr int NC_ = 96; CALL; } break; case 192: { constexpr int NC_ = 192; CALL; } break; case 384: { constexpr int NC_ = 384; CALL; } break; case 768: { constexpr int NC_ = 768; CALL; } break;
+#else
+#define VPS_PENCIL_FAMILY_2(CALL)
+#endif
+#define VPS_DISPATCH_PENCIL(NCVAL, CALL) \
+  switch (NCVAL) {                       \
+    VPS_PENCIL_FAMILY_0(CALL)            \
+    VPS_PENCIL_FAMILY_1(CALL)            \
+    VPS_PENCIL_FAMILY_2(CALL)            \
+    default: rc = VPS_PART_NOT_MINE;     \
+  }
+
+int VPS_PARTFN(vps_fftpart_tw)(int NC, std::vector<cf>* st) {
+  int rc = VPS_OK;
+  VPS_DISPATCH_NC(NC, build_stage_tw<NC_>(*st));
+  return rc;
+}
+
+int VPS_PARTFN(vps_fftpart_transpose)(vps_ctx* ctx, int NC, int real, const void* params, int kind) {
+  const PassParams& p = *static_cast<const PassParams*>(params);
+  int rc = VPS_OK;
+  if (real) {
+    VPS_DISPATCH_NC(NC, (rc = launch_transpose<NC_, true>(ctx, p, kind)));
+  } else {
+    VPS_DISPATCH_NC(NC, (rc = launch_transpose<NC_, false>(ctx, p, kind)));
+  }
+  return rc;
+}
+
+int VPS_PARTFN(vps_fftpart_x)(vps_ctx* ctx, int NC, int mode, int count, const void* params, int fast) {
+  const XParams& p = *static_cast<const XParams*>(params);
+  int rc = VPS_OK;
+  if (mode == 0 && count) {
+    VPS_DISPATCH_NC(NC, (rc = launch_x<NC_, 0, true>(ctx, p, fast != 0)));
+  } else if (mode == 0) {
+    VPS_DISPATCH_NC(NC, (rc = launch_x<NC_, 0, false>(ctx, p, fast != 0)));
+  } else if (mode == 1) {
+    VPS_DISPATCH_NC(NC, (rc = launch_x<NC_, 1>(ctx, p)));
+  } else if (mode == 2) {
+    VPS_DISPATCH_NC(NC, (rc = launch_x<NC_, 2>(ctx, p)));
+  } else {
+    VPS_DISPATCH_NC(NC, (rc = launch_x<NC_, 4>(ctx, p)));
+  }
+  return rc;
+}
+
+long long VPS_PARTFN(vps_fftpart_pencil_lds)(int NC) {
+  long long rc = VPS_PART_NOT_MINE;
+  long long lds = -1;
+  VPS_DISPATCH_PENCIL(NC, (lds = (long long)pencil_lds_bytes<NC_>(), rc = 0));
+  return rc == 0 ? lds : (long long)VPS_PART_NOT_MINE;
+}
+
+int VPS_PARTFN(vps_fftpart_pencil)(vps_ctx* ctx, int NC, const void* params, long long npencils) {
+  const PencilParams& p = *static_cast<const PencilParams*>(params);
+  int rc = VPS_OK;
+  VPS_DISPATCH_PENCIL(NC, (rc = launch_pencil<NC_>(ctx, p, npencils)));
+  return rc;
+}
+
+#if VPS_FFT_PART <= 0   // ---- API, tables and routing: part 0 (or the single-unit build) only ----
+#if VPS_FFT_PART == -1
+#define VPS_FOR_PARTS(X) X(_all)
+#else
+#define VPS_FOR_PARTS(X) X(_p0) X(_p1) X(_p2) X(_p3)
+#endif
+#define VPS_DECL_PART(sfx)                                                                         \
+  int VPS_CAT(vps_fftpart_tw, sfx)(int, std::vector<cf>*);                                          \
+  int VPS_CAT(vps_fftpart_transpose, sfx)(vps_ctx*, int, int, const void*, int);                    \
+  int VPS_CAT(vps_fftpart_x, sfx)(vps_ctx*, int, int, int, const void*, int);                       \
+  long long VPS_CAT(vps_fftpart_pencil_lds, sfx)(int);                                              \
+  int VPS_CAT(vps_fftpart_pencil, sfx)(vps_ctx*, int, const void*, long long);
+VPS_FOR_PARTS(VPS_DECL_PART)
+
+static int route_tw(vps_ctx* ctx, int NC, std::vector<cf>* st) {
+  int rc;
+#define VPS_TRY(sfx) if ((rc = VPS_CAT(vps_fftpart_tw, sfx)(NC, st)) != VPS_PART_NOT_MINE) return rc;
+  VPS_FOR_PARTS(VPS_TRY)
+#undef VPS_TRY
+  return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "unsupported FFT length %d", NC);
+}
+static int route_transpose(vps_ctx* ctx, int NC, int real, const PassParams& p, int kind) {
+  int rc;
+#define VPS_TRY(sfx) if ((rc = VPS_CAT(vps_fftpart_transpose, sfx)(ctx, NC, real, &p, kind)) != VPS_PART_NOT_MINE) return rc;
+  VPS_FOR_PARTS(VPS_TRY)
+#undef VPS_TRY
+  return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "unsupported FFT length %d", NC);
+}
+static int route_x(vps_ctx* ctx, int NC, int mode, int count, const XParams& p, int fast) {
+  int rc;
+#define VPS_TRY(sfx) if ((rc = VPS_CAT(vps_fftpart_x, sfx)(ctx, NC, mode, count, &p, fast)) != VPS_PART_NOT_MINE) return rc;
+  VPS_FOR_PARTS(VPS_TRY)
+#undef VPS_TRY
+  return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "unsupported FFT length %d", NC);
+}
+static long long route_pencil_lds(int NC) {
+  long long r;
+#define VPS_TRY(sfx) if ((r = VPS_CAT(vps_fftpart_pencil_lds, sfx)(NC)) != VPS_PART_NOT_MINE) return r;
+  VPS_FOR_PARTS(VPS_TRY)
+#undef VPS_TRY
+  return -1;
+}
+static int route_pencil(vps_ctx* ctx, int NC, const PencilParams& p, long long npencils) {
+  int rc;
+#define VPS_TRY(sfx) if ((rc = VPS_CAT(vps_fftpart_pencil, sfx)(ctx, NC, &p, npencils)) != VPS_PART_NOT_MINE) return rc;
+  VPS_FOR_PARTS(VPS_TRY)
+#undef VPS_TRY
+  return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "pencil path: no kernel for lines of %d points", NC);
+}
+
 int vps_fft_get_tables(vps_ctx* ctx, int NC, vps_fft_tables* out) {
   auto it = ctx->fft_tables.find(NC);
   if (it != ctx->fft_tables.end()) {
@@ -1321,8 +1466,7 @@ int vps_fft_get_tables(vps_ctx* ctx, int NC, vps_fft_tables* out) {
     return VPS_OK;
   }
   std::vector<cf> st;
-  int rc = VPS_OK;
-  VPS_DISPATCH_NC(NC, build_stage_tw<NC_>(st));
+  int rc = route_tw(ctx, NC, &st);
   if (rc) return rc;
   std::vector<cf> r2c(NC);
   for (int k = 0; k < NC; ++k) {
@@ -1394,7 +1538,7 @@ int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev, void* spec_d
   pz.B = nx;
   pz.tw_stage = tz.tw_stage;
   pz.tw_r2c = tz.tw_r2c;
-  VPS_DISPATCH_NC(NH, (rc = launch_transpose<NC_, true>(ctx, pz, VPS_K_FFT_Z)));
+  rc = route_transpose(ctx, NH, 1, pz, VPS_K_FFT_Z);
   if (rc) return rc;
 
   // y pass: lines (a = x, b = kz) of B[x][kz][:] -> C[kz][ky][x]
@@ -1408,7 +1552,7 @@ int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev, void* spec_d
   py.A = nx;
   py.B = NH;
   py.tw_stage = ty.tw_stage;
-  VPS_DISPATCH_NC(N, (rc = launch_transpose<NC_, false>(ctx, py, VPS_K_FFT_Y)));
+  rc = route_transpose(ctx, N, 0, py, VPS_K_FFT_Y);
   if (rc) return rc;
   // Nyquist plane: lines (a = x, b = 0) of BN[x][:] -> CN[ky][x]
   PassParams pn = py;
@@ -1418,7 +1562,7 @@ int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev, void* spec_d
   pn.in_sb = 0;
   pn.out_ob = 0;
   pn.B = 1;
-  VPS_DISPATCH_NC(N, (rc = launch_transpose<NC_, false>(ctx, pn, VPS_K_FFT_Y)));
+  rc = route_transpose(ctx, N, 0, pn, VPS_K_FFT_Y);
   return rc;
 }
 
@@ -1440,7 +1584,7 @@ static int fft_y_of(vps_ctx* ctx, int N, int nx, const cf* B, const cf* BN, void
   py.A = nx;
   py.B = NH;
   py.tw_stage = ty.tw_stage;
-  VPS_DISPATCH_NC(N, (rc = launch_transpose<NC_, false>(ctx, py, VPS_K_FFT_Y)));
+  rc = route_transpose(ctx, N, 0, py, VPS_K_FFT_Y);
   if (rc) return rc;
   PassParams pn = py;
   pn.in = BN;
@@ -1449,7 +1593,7 @@ static int fft_y_of(vps_ctx* ctx, int N, int nx, const cf* B, const cf* BN, void
   pn.in_sb = 0;
   pn.out_ob = 0;
   pn.B = 1;
-  VPS_DISPATCH_NC(N, (rc = launch_transpose<NC_, false>(ctx, pn, VPS_K_FFT_Y)));
+  rc = route_transpose(ctx, N, 0, pn, VPS_K_FFT_Y);
   return rc;
 }
 
@@ -1457,23 +1601,9 @@ int vps_pencil_tp(void) { return PENCIL_TP; }
 
 bool vps_pencil_supported(vps_ctx* ctx, int N) {
   if (!vps_fft_supported(N) || N < 64 || N > 2048) return false;
-  size_t lds = 0;
-  int rc = VPS_OK;
-  (void)rc;
-  switch (N / 2) {
-    case 32: lds = pencil_lds_bytes<32>(); break;
-    case 64: lds = pencil_lds_bytes<64>(); break;
-    case 128: lds = pencil_lds_bytes<128>(); break;
-    case 256: lds = pencil_lds_bytes<256>(); break;
-    case 512: lds = pencil_lds_bytes<512>(); break;
-    case 1024: lds = pencil_lds_bytes<1024>(); break;
-    case 96: lds = pencil_lds_bytes<96>(); break;
-    case 192: lds = pencil_lds_bytes<192>(); break;
-    case 384: lds = pencil_lds_bytes<384>(); break;
-    case 768: lds = pencil_lds_bytes<768>(); break;
-    default: return false;
-  }
-  return lds <= ctx->lds_per_cu;
+  const long long lds = route_pencil_lds(N / 2);
+  if (lds < 0) return false;
+  return (size_t)lds <= ctx->lds_per_cu;
 }
 
 // records sorted by pencil -> ncomp half spectra after the z and y passes
@@ -1504,19 +1634,7 @@ int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, cons
   p.tw_stage = tz.tw_stage;
   p.tw_r2c = tz.tw_r2c;
   const long long npencils = (long long)nx * p.nby;
-  switch (NH) {
-    case 32: rc = launch_pencil<32>(ctx, p, npencils); break;
-    case 64: rc = launch_pencil<64>(ctx, p, npencils); break;
-    case 128: rc = launch_pencil<128>(ctx, p, npencils); break;
-    case 256: rc = launch_pencil<256>(ctx, p, npencils); break;
-    case 512: rc = launch_pencil<512>(ctx, p, npencils); break;
-    case 1024: rc = launch_pencil<1024>(ctx, p, npencils); break;
-    case 96: rc = launch_pencil<96>(ctx, p, npencils); break;
-    case 192: rc = launch_pencil<192>(ctx, p, npencils); break;
-    case 384: rc = launch_pencil<384>(ctx, p, npencils); break;
-    case 768: rc = launch_pencil<768>(ctx, p, npencils); break;
-    default: rc = vps_fail(ctx, VPS_ERR_UNSUPPORTED, "pencil path: N=%d", N);
-  }
+  rc = route_pencil(ctx, NH, p, npencils);
   if (rc) return rc;
   cf* spec = reinterpret_cast<cf*>(spec_dev);
   cf* nyq = reinterpret_cast<cf*>(nyq_dev);
@@ -1571,18 +1689,18 @@ static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz
     p.nsample = nsample_dev;
     p.pair = (ctx->bin_fast && line0 % N == 0 && nlines % N == 0 && !getenv("VPS_NO_PAIR_BINNING")) ? 1 : 0;
     if (mode == 0) {
-      VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 0, true>(ctx, p, ctx->bin_fast)));
+      rc = route_x(ctx, N, 0, 1, p, ctx->bin_fast ? 1 : 0);
     } else {
-      VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 0, false>(ctx, p, ctx->bin_fast)));
+      rc = route_x(ctx, N, 0, 0, p, ctx->bin_fast ? 1 : 0);
     }
   } else if (mode == 1) {
     if (!out_dev) return vps_fail(ctx, VPS_ERR_ARG, "null output");
-    VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 1>(ctx, p)));
+    rc = route_x(ctx, N, 1, 0, p, 0);
   } else if (mode == 2) {
     if (!out_dev) return vps_fail(ctx, VPS_ERR_ARG, "null output");
-    VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 2>(ctx, p)));
+    rc = route_x(ctx, N, 2, 0, p, 0);
   } else if (mode == 4) {
-    VPS_DISPATCH_NC(N, (rc = launch_x<NC_, 4>(ctx, p)));
+    rc = route_x(ctx, N, 4, 0, p, 0);
   } else {
     return vps_fail(ctx, VPS_ERR_ARG, "mode must be 0..4");
   }
@@ -1652,3 +1770,5 @@ int vps_power_grid(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, 
 }
 
 }  // extern "C"
+
+#endif   // VPS_FFT_PART <= 0

@@ -75,6 +75,9 @@ KERNEL_KINDS = {"deposit": K_DEPOSIT, "algebra": K_ALGEBRA, "fft_z": K_FFT_Z, "f
                 "fft_x": K_FFT_X, "nn_build": K_NN_BUILD, "nn_query": K_NN_QUERY, "misc": K_MISC}
 
 
+FFT_PARTS = 4   # fft.hip is compiled once per family of line lengths (-DVPS_FFT_PART=k)
+
+
 class VpsError(RuntimeError):
     pass
 
@@ -90,13 +93,20 @@ def build(force=False, verbose=False):
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []
+    units = []
     for s in srcs:
-        o = os.path.join(objdir, os.path.basename(s).replace(".hip", ".o"))
+        stem = os.path.basename(s).replace(".hip", "")
+        if stem == "fft":
+            # one object per family of line lengths (fft.hip: "translation-unit split"), compiled side by side
+            units += [(s, os.path.join(objdir, "fft_p%d.o" % k), ["-DVPS_FFT_PART=%d" % k]) for k in range(FFT_PARTS)]
+        else:
+            units.append((s, os.path.join(objdir, stem + ".o"), []))
+    for s, o, extra in units:
         objs.append(o)
         if not force and os.path.exists(o) and os.path.getmtime(o) >= max(
                 os.path.getmtime(s), os.path.getmtime(deps[-1]), os.path.getmtime(deps[-2])):
             continue
-        cmd = [hipcc, *HIPCC_FLAGS, "-c", s, "-o", o]
+        cmd = [hipcc, *HIPCC_FLAGS, *extra, "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -11,6 +11,8 @@ mkdir -p $root/tools/exp_libs /tmp/vps_variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -I$csrc -I$root/include "$@" -c -x hip $src -o /tmp/vps_variants/${unit}_$name.o
 objs=""
 for u in api deposit fft hist nn preprocess; do
-  if [ $u = $unit ]; then objs="$objs /tmp/vps_variants/${unit}_$name.o"; else objs="$objs $csrc/build/$u.o"; fi
+  if [ $u = $unit ]; then objs="$objs /tmp/vps_variants/${unit}_$name.o";      # (a variant fft.hip is ONE unit: VPS_FFT_PART = -1)
+  elif [ $u = fft ]; then objs="$objs $csrc/build/fft_p0.o $csrc/build/fft_p1.o $csrc/build/fft_p2.o $csrc/build/fft_p3.o";
+  else objs="$objs $csrc/build/$u.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/tools/exp_libs/lib_$name.so $objs
