@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -271,13 +272,14 @@ class HipKernels:
         work = self.workspace("fused", self.lib.vps_deposit_fft_zy_workspace_bytes(pos.shape[0], N, nx))
         # reuse_sort (a token returned by an earlier call): several quantities of the SAME particle tensors -- the
         # bucketed records of that call are still in the workspace if nothing else has used it since, and then
-        # only the first call sorts.  The token pins the tensors (their addresses cannot be recycled) and
-        # records their in-place modification counters; any mismatch silently sorts again.
-        state = (pos, vel, rho, pos._version, vel._version, rho._version, int(N), float(Lbox), int(x0), int(nx),
-                 work.data_ptr())
+        # only the first call sorts.  The token holds WEAK references to the tensors (a freed tensor whose address
+        # is recycled cannot pass for the old one, and nothing is kept alive by the library) and records their
+        # in-place modification counters; any mismatch silently sorts again.
+        state = (weakref.ref(pos), weakref.ref(vel), weakref.ref(rho), pos._version, vel._version, rho._version,
+                 int(N), float(Lbox), int(x0), int(nx), work.data_ptr())
         last = getattr(self, "_fused_token", None)
-        if (reuse_sort is not None and reuse_sort is last and all(a is b for a, b in zip(last[:3], state[:3]))
-                and last[3:] == state[3:]):
+        if (reuse_sort is not None and reuse_sort is last
+                and all(r() is t for r, t in zip(last[:3], (pos, vel, rho))) and last[3:] == state[3:]):
             flags |= FLAG_REUSE_SORT
         self._fused_token = state
         self._chk(self.lib.vps_deposit_fft_zy(self.ctx, self._ptr(pos), self._pos_kind(pos),
