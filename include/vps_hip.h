@@ -166,6 +166,10 @@ int vps_nn_resample(vps_ctx* ctx, const void* pos_dev, int pos_is_f64,
  * With VPS_FLAG_INPUT_IS_VM the channels are taken as vx,vy,vz,mass instead.        */
 int vps_field_algebra(vps_ctx* ctx, int quantity, int flags, double Lcell,
                       float* chans_dev, int64_t ncell);
+/* Out-of-place form: chans_dev is only read, the result's channels (3: velocity / momentum, 1: energy,
+ * 4: VM) go to out_dev[c][ncell]; out_dev == NULL is the in-place call above. */
+int vps_field_algebra_out(vps_ctx* ctx, int quantity, int flags, double Lcell, const float* chans_dev,
+                          int64_t ncell, float* out_dev);
 
 /* ---- stage B+C: 3-D R2C FFT, |f|^2, shell binning ------------------------ */
 /* Supported N: powers of two, 16 <= N <= 4096; 96, 192, 384, 768, 1536 (radix 3 / 6 / 12 / 24);

@@ -628,10 +628,13 @@ __global__ void __launch_bounds__(256)
 
 // In-place algebra on an existing 4-channel grid (used after the NN resample and by
 // BoxField.spctrm on user-supplied fields).
+// `out` == nullptr: in place; else the channels of the result go to out[c][ncell] and ch is only read
+// (a second quantity of the same field: no copy of the four input channels is needed).
 __global__ void __launch_bounds__(256)
-    field_algebra_kernel(float* __restrict__ ch, long long ncell, int quantity, int flags, float vol) {
+    field_algebra_kernel(float* ch, long long ncell, int quantity, int flags, float vol, float* out) {
   const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i0 >= ncell) return;
+  float* dst = out ? out : ch;
   float4 a = *reinterpret_cast<float4*>(ch + i0);
   float4 b = *reinterpret_cast<float4*>(ch + ncell + i0);
   float4 c = *reinterpret_cast<float4*>(ch + 2 * ncell + i0);
@@ -645,12 +648,12 @@ __global__ void __launch_bounds__(256)
   a.z = r[0]; b.z = r[1]; c.z = r[2]; m.z = r[3];
   algebra_cell(a.w, b.w, c.w, m.w, quantity, flags, vol, r);
   a.w = r[0]; b.w = r[1]; c.w = r[2]; m.w = r[3];
-  *reinterpret_cast<float4*>(ch + i0) = a;
+  *reinterpret_cast<float4*>(dst + i0) = a;
   if (quantity != VPS_ENERGY) {
-    *reinterpret_cast<float4*>(ch + ncell + i0) = b;
-    *reinterpret_cast<float4*>(ch + 2 * ncell + i0) = c;
+    *reinterpret_cast<float4*>(dst + ncell + i0) = b;
+    *reinterpret_cast<float4*>(dst + 2 * ncell + i0) = c;
   }
-  if (quantity == VPS_VM) *reinterpret_cast<float4*>(ch + 3 * ncell + i0) = m;
+  if (quantity == VPS_VM) *reinterpret_cast<float4*>(dst + 3 * ncell + i0) = m;
 }
 
 // [rho vx, rho vy, rho vz, rho] per particle (interp.py:199-213)
@@ -1019,8 +1022,16 @@ int vps_density_velocity_vector(vps_ctx* ctx, const float* vel_dev, const float*
   return VPS_OK;
 }
 
+int vps_field_algebra_out(vps_ctx* ctx, int quantity, int flags, double Lcell, const float* chans_dev,
+                          int64_t ncell, float* out_dev);
+
 int vps_field_algebra(vps_ctx* ctx, int quantity, int flags, double Lcell, float* chans_dev,
                       int64_t ncell) {
+  return vps_field_algebra_out(ctx, quantity, flags, Lcell, chans_dev, ncell, nullptr);
+}
+
+int vps_field_algebra_out(vps_ctx* ctx, int quantity, int flags, double Lcell, const float* chans_dev,
+                          int64_t ncell, float* out_dev) {
   if (!ctx) return VPS_ERR_ARG;
   if (quantity < 0 || quantity > 3) return vps_fail(ctx, VPS_ERR_ARG, "vps_field_algebra: quantity %d", quantity);
   if (ncell < 0 || (ncell & 3)) return vps_fail(ctx, VPS_ERR_ARG, "vps_field_algebra: ncell must be a multiple of 4");
@@ -1030,8 +1041,8 @@ int vps_field_algebra(vps_ctx* ctx, int quantity, int flags, double Lcell, float
   const unsigned blocks = (unsigned)((nthreads + 255) / 256);
   {
     vps_launch_timer tm(ctx, VPS_K_ALGEBRA);
-    hipLaunchKernelGGL(field_algebra_kernel, dim3(blocks), dim3(256), 0, ctx->stream, chans_dev,
-                       (long long)ncell, quantity, flags, (float)(Lcell * Lcell * Lcell));
+    hipLaunchKernelGGL(field_algebra_kernel, dim3(blocks), dim3(256), 0, ctx->stream, const_cast<float*>(chans_dev),
+                       (long long)ncell, quantity, flags, (float)(Lcell * Lcell * Lcell), out_dev);
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
   return VPS_OK;

@@ -314,6 +314,16 @@ class HipKernels:
         self._chk(self.lib.vps_field_algebra(self.ctx, quantity, flags, float(Lcell),
                                              self._ptr(chans, torch.float32), ncell))
 
+    def field_algebra_out(self, chans, quantity, flags, Lcell):
+        """Fields of `quantity` from the four channels, which are left untouched: -> [3 | 1 | 4, ...] float32."""
+        self._stream()
+        ncell = chans[0].numel()
+        nout = 1 if quantity == ENERGY else (4 if quantity == VM else 3)
+        out = self.empty((nout,) + tuple(chans.shape[1:]), torch.float32)
+        self._chk(self.lib.vps_field_algebra_out(self.ctx, quantity, flags, float(Lcell),
+                                                 self._ptr(chans, torch.float32), ncell, self._ptr(out)))
+        return out
+
     # -- stage B + C ------------------------------------------------------------
     def fft_supported(self, N):
         return bool(self.lib.vps_fft_supported(int(N)))

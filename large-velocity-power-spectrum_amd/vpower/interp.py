@@ -252,12 +252,10 @@ class BoxField:
         if quantity == "momentum":
             if REFERENCE_COMPAT["momentum_bug"]:
                 flags |= _dev.FLAG_REFERENCE_MOMENTUM_BUG
-            work = ch.clone()
-            k.field_algebra(work, _dev.MOMENTUM, flags, self.Lcell)
+            work = k.field_algebra_out(ch, _dev.MOMENTUM, flags, self.Lcell)     # (no copy of the four channels)
             return [work[0], work[1], work[2]]
         if quantity == "energy":
-            work = ch.clone()
-            k.field_algebra(work, _dev.ENERGY, flags, self.Lcell)
+            work = k.field_algebra_out(ch, _dev.ENERGY, flags, self.Lcell)
             return [work[0]]
         raise Exception("""Unrecognized physical quantity name.
         Supported: 'velocity', 'momentum', 'energy'.""")
