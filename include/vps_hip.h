@@ -195,6 +195,10 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host,
 size_t vps_fft_workspace_bytes(int N, int nx);
 int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev,
                void* spec_dev, void* nyq_dev, void* work_dev);
+/* The same for the product field_dev * weight_dev (cell by cell; weight_dev NULL = vps_fft_zy): momentum
+ * components v_c * mass of a gridded field (interp.py:523-525) without a separate algebra pass. */
+int vps_fft_zy_weighted(vps_ctx* ctx, int N, int nx, const float* field_dev, const float* weight_dev,
+                        void* spec_dev, void* nyq_dev, void* work_dev);
 
 /* x pass over `nlines` lines of length N.  Line i is made of nseg segments of
  * N/nseg contiguous complex64: element x of line i lives at

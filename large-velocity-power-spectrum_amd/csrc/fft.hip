@@ -462,6 +462,8 @@ __device__ __forceinline__ int out_index(int l, int i) {
 
 struct PassParams {
   const void* in;
+  const void* in_w;          // REAL passes: optional second real field of the same layout; the line transformed is in * in_w
+                             // (momentum p_c = v_c * mass of a gridded field without a separate algebra pass)
   void* out;
   void* out_nyq;
   long long in_sa, in_sb;  // input strides of the tile axis a and batch axis b (elements)
@@ -576,6 +578,17 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
 #pragma unroll
         for (int r = 0; r < R; ++r)
           v[m * R + r] = live ? load_stream(&src[l + L * m + r * (NC / R)]) : make_float2(0.f, 0.f);
+      if (p.in_w) {
+        const cf* srcw = reinterpret_cast<const cf*>(reinterpret_cast<const float*>(p.in_w) +
+                                                      (long long)b * p.in_sb + (long long)(a0 + t) * p.in_sa);
+#pragma unroll
+        for (int m = 0; m < NB; ++m)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const cf w = live ? srcw[l + L * m + r * (NC / R)] : make_float2(0.f, 0.f);
+            v[m * R + r] = make_float2(v[m * R + r].x * w.x, v[m * R + r].y * w.y);
+          }
+      }
     } else {
       const cf* src = reinterpret_cast<const cf*>(p.in) + (long long)b * p.in_sb +
                       (long long)(a0 + t) * p.in_sa;
@@ -1509,8 +1522,16 @@ size_t vps_power_workspace_bytes(int N) {
   return 2 * vps_fft_workspace_bytes(N, N);
 }
 
+int vps_fft_zy_weighted(vps_ctx* ctx, int N, int nx, const float* field_dev, const float* weight_dev,
+                        void* spec_dev, void* nyq_dev, void* work_dev);
+
 int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev, void* spec_dev, void* nyq_dev,
                void* work_dev) {
+  return vps_fft_zy_weighted(ctx, N, nx, field_dev, nullptr, spec_dev, nyq_dev, work_dev);
+}
+
+int vps_fft_zy_weighted(vps_ctx* ctx, int N, int nx, const float* field_dev, const float* weight_dev,
+                        void* spec_dev, void* nyq_dev, void* work_dev) {
   if (!ctx) return VPS_ERR_ARG;
   if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   if (nx < 1 || nx > N) return vps_fail(ctx, VPS_ERR_ARG, "nx=%d out of range", nx);
@@ -1527,6 +1548,7 @@ int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev, void* spec_d
   // z pass: lines (a = y, b = x) of R[x][y][:] -> B[x][kz][y], BN[x][y]
   PassParams pz{};
   pz.in = field_dev;
+  pz.in_w = weight_dev;
   pz.out = B;
   pz.out_nyq = BN;
   pz.in_sa = N;

@@ -60,6 +60,7 @@ SYMBOLS = (
     ("vps_set_binning", C.c_int, (_vp, C.c_int, _dp, _dp, C.c_int, C.c_double, C.c_double)),
     ("vps_fft_workspace_bytes", C.c_size_t, (C.c_int, C.c_int)),
     ("vps_fft_zy", C.c_int, (_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp)),
+    ("vps_fft_zy_weighted", C.c_int, (_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp)),
     ("vps_fft_x", C.c_int, (_vp, C.c_int, _i64, _i64, C.c_int, _vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp)),
     ("vps_fft_x_bin", C.c_int, (_vp, C.c_int, _i64, _i64, C.c_int, C.POINTER(_vp), C.c_int, C.c_int, _i64, C.c_int,
                                _vp, _vp)),

@@ -335,16 +335,17 @@ class HipKernels:
         self._chk(self.lib.vps_set_binning(self.ctx, N, _ffi.as_dp(k2), _ffi.as_dp(thr), len(thr) - 1,
                                            float(edge0), float(inv_spacing)))
 
-    def fft_zy(self, field, N, nx, spec=None, nyq=None):
-        """field [nx,N,N] float32 -> spec [N/2,N,nx], nyq [N,nx] (complex64)."""
+    def fft_zy(self, field, N, nx, spec=None, nyq=None, weight=None):
+        """field [nx,N,N] float32 (times `weight`, same shape, if given) -> spec [N/2,N,nx], nyq [N,nx] (complex64)."""
         self._stream()
         if spec is None:
             spec = self.empty((N // 2, N, nx), torch.complex64)
         if nyq is None:
             nyq = self.empty((N, nx), torch.complex64)
         work = self.workspace("fft", self.lib.vps_fft_workspace_bytes(N, nx))
-        self._chk(self.lib.vps_fft_zy(self.ctx, N, nx, self._ptr(field, torch.float32), self._ptr(spec),
-                                      self._ptr(nyq), self._ptr(work)))
+        self._chk(self.lib.vps_fft_zy_weighted(self.ctx, N, nx, self._ptr(field, torch.float32),
+                                               self._ptr(weight, torch.float32), self._ptr(spec), self._ptr(nyq),
+                                               self._ptr(work)))
         return spec, nyq
 
     def fft_x_bin(self, lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True):
@@ -528,7 +529,7 @@ class PowerPipeline:
         self.const = (self.Lbox / (2 * np.pi)) ** 1.5 / self.N ** 3   # interp.py:1381
 
     # -- stage B + C on one or more real fields of this rank's slab ---------------
-    def accumulate(self, fields, psum=None, nsample=None, count=True):
+    def accumulate(self, fields, psum=None, nsample=None, count=True, weight=None):
         """Add sum_w |F|^2 of every field ([nx,N,N] float32) into the shell sums, and (with
         `count`) the number of modes per shell into nsample -- once, on the first field: the
         reference histograms the component-summed P grid once (interp.py:1474-1477).
@@ -544,7 +545,7 @@ class PowerPipeline:
         # passes as the exchanges complete: communication overlaps the neighbouring fields' compute
         pending = []
         for f in fields:
-            spec, nyq = k.fft_zy(f, N, nx)
+            spec, nyq = k.fft_zy(f, N, nx) if weight is None else k.fft_zy(f, N, nx, weight=weight)
             pending.append((self.comm.all_to_all_start(spec), self.comm.all_to_all_start(nyq)))
         self._bin_exchanged(pending, psum, nsample, count)
         return psum, nsample
@@ -607,8 +608,9 @@ class PowerPipeline:
             P[ns == 0] = 0                      # interp.py:1479
         return np.column_stack((self.centers, P, ps, ns.astype(np.float64)))
 
-    def spectrum(self, fields):
-        psum, nsample = self.accumulate(fields)
+    def spectrum(self, fields, weight=None):
+        """P(k) table of the fields (each multiplied cell by cell by `weight` if given), times 4 pi k^2."""
+        psum, nsample = self.accumulate(fields, weight=weight)
         tab = self.finish(psum, nsample)
         tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2   # interp.py:590 / parallel_optimized.py:434
         return tab

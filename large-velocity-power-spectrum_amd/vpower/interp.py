@@ -296,6 +296,11 @@ class BoxField:
             tab = pipe.finish(*pipe.accumulate_spectra(spec, nyq))
             tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2
             return PowerSpectrum(tab)
+        if quantity == "momentum":
+            # p_c = v_c * mass is formed inside the z pass (two reads per line instead of an algebra pass)
+            ch = self._device_chans(k)
+            comps = [ch[0], ch[0], ch[0]] if REFERENCE_COMPAT["momentum_bug"] else [ch[0], ch[1], ch[2]]
+            return PowerSpectrum(pipe.spectrum(comps, weight=ch[3]))
         fields = self._fields(k, quantity)
         return PowerSpectrum(pipe.spectrum(fields))
 

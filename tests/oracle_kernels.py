@@ -28,8 +28,10 @@ class OracleKernels:
     def set_binning(self, N, k2, thr, edge0, inv_spacing):
         self.binning = (N, np.asarray(k2), np.asarray(thr))
 
-    def fft_zy(self, field, N, nx):
+    def fft_zy(self, field, N, nx, weight=None):
         f = field.numpy().astype(np.float64)
+        if weight is not None:
+            f = f * weight.numpy().astype(np.float64)
         assert f.shape == (nx, N, N)
         F = np.fft.fft(np.fft.rfft(f, axis=2), axis=1)       # [x, ky, kz<=N/2]
         F = np.ascontiguousarray(F.transpose(2, 1, 0)).astype(np.complex64)   # [kz, ky, x]

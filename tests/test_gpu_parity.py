@@ -509,6 +509,20 @@ def test_reuse_sort_is_safe_and_equal(K):
     assert all(float((g - r).abs().max()) <= 2e-5 * float(r.abs().max()) for g, r in zip(got, [t.clone() for t in fresh]))
 
 
+def test_weighted_z_pass_equals_algebra_then_z_pass(K):
+    """fft_zy(field, weight=mass) against the out-of-place momentum algebra followed by the plain z/y passes."""
+    from vpower import device
+    N, nx = 128, 32
+    rng = np.random.default_rng(21)
+    ch = K.to_device(rng.standard_normal((4, nx, N, N)).astype(np.float32))
+    p = K.field_algebra_out(ch, device.MOMENTUM, device.FLAG_INPUT_IS_VM, 1.0)       # p_c = v_c * mass (Lcell = 1)
+    for c in range(3):
+        s_ref, n_ref = [t.clone() for t in K.fft_zy(p[c], N, nx)]
+        s_w, n_w = K.fft_zy(ch[c], N, nx, weight=ch[3])
+        scale = float(s_ref.abs().pow(2).mean().sqrt())
+        assert float((s_w - s_ref).abs().max()) / scale < 1e-6 and float((n_w - n_ref).abs().max()) / scale < 1e-6
+
+
 def test_fused_pipeline_against_oracle(K):
     from vpower import device
     N, L, Np = 64, 1.0, 60000
