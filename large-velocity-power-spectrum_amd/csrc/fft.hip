@@ -1504,6 +1504,8 @@ void vps_fft_free_tables(vps_ctx* ctx) {
   ctx->fft_tables.clear();
 }
 
+static int fft_y_of(vps_ctx* ctx, int N, int nx, const cf* B, const cf* BN, void* spec_dev, void* nyq_dev);
+
 extern "C" {
 
 int vps_fft_supported(int N) {
@@ -1563,29 +1565,8 @@ int vps_fft_zy_weighted(vps_ctx* ctx, int N, int nx, const float* field_dev, con
   rc = route_transpose(ctx, NH, 1, pz, VPS_K_FFT_Z);
   if (rc) return rc;
 
-  // y pass: lines (a = x, b = kz) of B[x][kz][:] -> C[kz][ky][x]
-  PassParams py{};
-  py.in = B;
-  py.out = spec_dev;
-  py.in_sa = (long long)NH * N;
-  py.in_sb = N;
-  py.out_ob = (long long)N * nx;
-  py.out_ok = nx;
-  py.A = nx;
-  py.B = NH;
-  py.tw_stage = ty.tw_stage;
-  rc = route_transpose(ctx, N, 0, py, VPS_K_FFT_Y);
-  if (rc) return rc;
-  // Nyquist plane: lines (a = x, b = 0) of BN[x][:] -> CN[ky][x]
-  PassParams pn = py;
-  pn.in = BN;
-  pn.out = nyq_dev;
-  pn.in_sa = N;
-  pn.in_sb = 0;
-  pn.out_ob = 0;
-  pn.B = 1;
-  rc = route_transpose(ctx, N, 0, pn, VPS_K_FFT_Y);
-  return rc;
+  // y pass: lines (a = x, b = kz) of B[x][kz][:] -> C[kz][ky][x]; Nyquist plane BN[x][:] -> CN[ky][x]
+  return fft_y_of(ctx, N, nx, B, BN, spec_dev, nyq_dev);
 }
 
 }  // extern "C"
