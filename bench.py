@@ -1,103 +1,485 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path particles -> P(k) on MI355X, one process per GPU.
 
-    python bench.py [--gpus N --steps K --warmup W] [--config C2]
+    python bench.py [--gpus N --steps K --warmup W] [--config C4]
+
+`--gpus N` with N > 1 starts its own N ranks (a `python -m torch.distributed.run` child, before
+this process touches the GPU) unless it already runs under a launcher (WORLD_SIZE set):
+
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one full pass of the path over one synthetic particle set already resident in
-HBM: NGP deposit of [rho v, rho] into per-pencil buckets (rank, scan, scatter), one fused
-kernel that accumulates each pencil in LDS, forms v = rho v / rho and z-transforms it, three y passes + all-to-all (N>1) + x pass with fused |F|^2 shell binning, shell all-reduce,
-download of the (nbins,) sums, P(k) table.  Workload: BASELINE.json configs[1]
-(512^3 grid, 1e7 particles, velocity P(k), nearest-grid-point deposition); with N>1 the SAME
-grid is slab-decomposed over the N GPUs (strong scaling, one RCCL all-to-all per field).
+One "step" = one full pass of the path over one synthetic particle set already resident in HBM,
+for the quantities the config names (vpower.synth.WORKLOADS; BASELINE.json configs):
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+    C1  128^3,  1e5 particles: exact NN on the script lattice, raw velocities, script binning
+    C2  512^3,  1e7 particles: NGP deposit, velocity P(k)
+    C3  1024^3, 5e7 particles: exact-NN resampling (library lattice), momentum P(k)
+    C4  2048^3, 1e8 particles: NGP deposit, velocity + momentum + kinetic-energy P(k)   <- default
+    C5  4096^3, 1e9 particles: NGP deposit, kinetic-energy P(k) (needs 8 GPUs: 275 GB per real field)
+
+NGP route per quantity: bucket sort of the particle records by z-pencil (first quantity of a step
+only), one fused kernel that accumulates each pencil in LDS, forms v / p / E and z-transforms it,
+y passes, all-to-all (N > 1), x pass with fused |F|^2 shell binning, shell all-reduce, download of
+the (nbins,) sums, P(k) table.  With N > 1 the SAME grid is slab-decomposed over the N GPUs
+(strong scaling, one RCCL all-to-all per scalar field).
+
+Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" explains every field).  Besides the timed
+region the default run also (a) runs the SAME step function on a small sample of the workload and
+compares its tables with the CPU oracle (`parity`), (b) times the oracle on that sample on one
+core and on all cores (`cpu_baseline`, `cpu_baseline_allcores`), (c) at N = 1 with the default
+config, times short runs of C2 and C3 (`other_configs`).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "large-velocity-power-spectrum_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+PSUM_RTOL = 2e-5        # Psum per non-empty bin vs the float64 oracle
 
 
-def cpu_baseline(sample_N=256, density=10_000_000 / 512 ** 3):
-    """The oracle (numpy restatement of the reference, kind 'port') timed on this host on a
-    bounded sample of the same workload: same particle density, grid 256^3 instead of 512^3
-    (1/8 of the cells and particles), one core (the reference pins FFTW to threads=1,
-    vpower/interp.py:1382)."""
-    from oracle import vps_oracle as orc
-    from vpower import synth
-    Np = int(round(density * sample_N ** 3))
-    pos, vel, mass, dens = synth.particles(synth.BASE_SEED + 2, Np, 1.0)
-    t0 = time.perf_counter()
-    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
-    grid = orc.deposit_to_grid_fast(vec, pos, sample_N, 1.0)
-    v, m = orc.vm_from_vec_grid(grid, 1.0 / sample_N, zero_empty=True)
-    t1 = time.perf_counter()
-    P = orc.vector_power(v[..., 0], v[..., 1], v[..., 2], 1.0, sample_N)
-    t2 = time.perf_counter()
-    orc.spectrum_table(P, 1.0, sample_N, "library")
-    t3 = time.perf_counter()
-    total = t3 - t0
-    if sample_N < 512 and total < 4.0:
-        # fast host: the 1/8 sample is too short to time, run the whole workload instead
-        return cpu_baseline(512, density)
-    frac = "the whole workload" if sample_N == 512 else "1/8 of the workload at equal particle density"
-    return {
-        "value": sample_N ** 3 * 3 / total, "unit": "grid cells*components/s", "cores": 1, "kind": "port",
-        "sample": "oracle/vps_oracle.py on %d^3 cells, %d particles (%s), float64, 1 thread: "
-                  "deposit %.2fs, 3 FFTs+power %.2fs, pair+hist %.2fs"
-                  % (sample_N, Np, frac, t1 - t0, t2 - t1, t3 - t2),
-        "seconds": total,
-    }
-
-
-def baseline_metric():
-    """BASELINE.json's metric string, verbatim (the file travels with the repo)."""
-    try:
-        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-    except Exception:
-        return "particles gridded/s + 3D FFT cells/s (Ngrid\u00b3) at 1/2/4/8 GPUs; HBM % of roofline"
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C2", help="C1..C5 of vpower.synth.CONFIGS (grid, particles)")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C4", help="C1..C5 (vpower.synth.CONFIGS / WORKLOADS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--unfused", action="store_true", help="separate deposit and z-pass kernels (grid through HBM)")
-    ap.add_argument("--profile-steps", type=int, default=5, help="extra instrumented steps for the roofline")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short C2 / C3 runs of the default line")
+    ap.add_argument("--unfused", action="store_true", help="NGP route: separate deposit and z-pass kernels (grid through HBM)")
+    ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the roofline")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="diagnostic: time ONE rank's share of a G-rank slab decomposition on one GPU "
                          "(x-slab N/G, segmented x pass, exchanges skipped; the spectrum is not meaningful)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check: every rank joins a gloo group, all-reduces its rank and rank 0 prints "
+                         "{'dry_run': true, 'n_gpus': N}; no GPU is touched")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="with --dry-run: this rank exits with code 3")
+    return ap.parse_args(argv)
+
+
+def dry_run(args):
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        return 2
+    if rank == args.dry_run_fail_rank:
+        return 3
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": float(t.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child
+    `torch.distributed.run` and relay its output and exit code.  This process has not imported
+    torch yet, so it never touches the GPU; nothing is re-exec'ed."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------
+# the workload: device step and CPU oracle of the same quantities
+# ------------------------------------------------------------------------------------------------
+def baseline_json():
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    except Exception:
+        return {"metric": "particles gridded/s + 3D FFT cells/s (Ngrid³) at 1/2/4/8 GPUs; HBM % of roofline",
+                "configs": []}
+
+
+NCOMP = {"velocity": 3, "momentum": 3, "energy": 1}
+
+
+class Workload:
+    """One config's step on the device: particles resident in HBM -> {quantity: (nbins,4) table}.
+    The same class runs the timed region, the instrumented steps and the small oracle-checked
+    sample, so what is checked is what is timed."""
+
+    def __init__(self, K, comm, N, L, route, quantities, flavour, pos, vel, rho, unfused=False):
+        import torch
+        from vpower import device
+        self.K, self.comm, self.N, self.L = K, comm, int(N), float(L)
+        self.route, self.quantities, self.flavour = route, tuple(quantities), flavour
+        self.pos, self.vel, self.rho = pos, vel, rho
+        self.dev = device
+        self.pipe = device.PowerPipeline(N, L, kernels=K, comm=comm, flavour=flavour)
+        self.nx, self.x0 = self.pipe.nx, self.pipe.x0
+        self.psum, self.nsample = self.pipe.new_accumulators()
+        self.acc_buf = self.pipe._acc_buf
+        nx = self.nx
+        maxc = max(NCOMP[q] for q in self.quantities)
+        if route == "ngp":
+            self.fused = (not unfused) and all(K.fused_supported(N, device.QUANTITY[q]) for q in self.quantities)
+            if self.fused:
+                self.spec = K.empty((maxc, N // 2, N, nx), torch.complex64)
+                self.nyq = K.empty((maxc, N, nx), torch.complex64)
+            else:
+                self.grid = K.empty((maxc, nx, N, N), torch.float32)
+        elif route == "nn":
+            self.fused = False
+            Lcell = self.L / N
+            ax = np.linspace(Lcell / 2, self.L + Lcell / 2, N)      # interp.py:1063
+            self.axes = (ax, ax, ax)
+            self.grid = K.empty((4, nx, N, N), torch.float32)
+        elif route == "script":
+            self.fused = False
+            lcell = self.L / N
+            ax = np.array([i * lcell for i in range(N)], dtype=np.float32).astype(np.float64)   # script:343-346
+            self.axes = (ax, ax, ax)
+            self.grid = K.empty((3, nx, N, N), torch.float32)
+        else:
+            raise SystemExit("unknown route %r" % route)
+
+    def fields_per_step(self):
+        return sum(NCOMP[q] for q in self.quantities)
+
+    def describe_path(self):
+        if self.route == "ngp":
+            return "fused deposit+z pass (pencil buckets)" if self.fused else "deposit -> grid -> z pass"
+        if self.route == "nn":
+            return "exact-NN resample (library lattice) -> [rho v, rho] grid -> v, m -> z pass (p = v*m formed in the pass)"
+        return "exact-NN resample (script lattice, raw velocities) -> grid -> z pass"
+
+    def _table(self):
+        tab = self.pipe.finish(self.psum, self.nsample)     # all-reduce, D2H, table
+        tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2              # interp.py:590 / script:434
+        return tab
+
+    def step(self):
+        K, dev, N, L, nx, x0 = self.K, self.dev, self.N, self.L, self.nx, self.x0
+        out = {}
+        if self.route == "ngp":
+            token = None
+            for q in self.quantities:
+                qi, nc = dev.QUANTITY[q], NCOMP[q]
+                self.acc_buf.zero_()
+                if self.fused:
+                    # deposit + field algebra + z pass in one kernel (pencil buckets), then the y passes;
+                    # the second and third quantity of a step reuse the first one's bucket sort
+                    spec, nyq = K.deposit_fft_zy(self.pos, self.vel, self.rho, N, L, x0, nx, qi,
+                                                 spec=self.spec[:nc], nyq=self.nyq[:nc], reuse_sort=token)
+                    token = K.fused_token()
+                    self.pipe.accumulate_spectra(spec, nyq, self.psum, self.nsample)
+                else:
+                    g = K.deposit_field(self.pos, self.vel, self.rho, N, L, x0, nx, qi, out=self.grid[:nc])
+                    self.pipe.accumulate([g[i] for i in range(nc)], self.psum, self.nsample)
+                out[q] = self._table()
+            return out
+        if self.route == "nn":
+            payload = K.density_velocity_vector(self.vel, self.rho)              # interp.py:199-213
+            g, _ = K.nn_resample(self.pos, payload, self.axes, x0, nx, out=self.grid)
+            K.field_algebra(g, dev.VM, 0, L / N)                                  # interp.py:272-273
+            for q in self.quantities:
+                self.acc_buf.zero_()
+                if q == "momentum":
+                    self.pipe.accumulate([g[0], g[1], g[2]], self.psum, self.nsample, weight=g[3])
+                elif q == "velocity":
+                    self.pipe.accumulate([g[0], g[1], g[2]], self.psum, self.nsample)
+                else:
+                    e = K.field_algebra_out(g, dev.ENERGY, dev.FLAG_INPUT_IS_VM, L / N)
+                    self.pipe.accumulate([e[0]], self.psum, self.nsample)
+                out[q] = self._table()
+            return out
+        # script route: raw velocity gather (script:351), complex64 powers (:409-411), float32 table (:436-463)
+        g, _ = K.nn_resample(self.pos, self.vel, self.axes, x0, nx, out=self.grid)
+        self.acc_buf.zero_()
+        self.pipe.accumulate([g[0], g[1], g[2]], self.psum, self.nsample)
+        tab = np.array(self._table(), dtype=np.float32)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            tab[:, 1] = tab[:, 2] / tab[:, 3] * (4 * np.pi * tab[:, 0] ** 2)
+        out["velocity"] = tab
+        return out
+
+
+def oracle_tables(route, quantities, flavour, N, L, pos, vel, dens):
+    """The CPU oracle (oracle/vps_oracle.py: numpy restatement of the reference) on the same
+    particles -> ({quantity: table}, {stage: seconds})."""
+    from oracle import vps_oracle as orc
+    t = {}
+    t0 = time.perf_counter()
+    if route == "script":
+        tab, _ = orc.script_pipeline(pos, vel, N, L)
+        t["total"] = time.perf_counter() - t0
+        return {"velocity": tab}, t
+    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
+    if route == "ngp":
+        grid = orc.deposit_to_grid_fast(vec, pos, N, L)
+        v, m = orc.vm_from_vec_grid(grid, L / N, zero_empty=True)
+    else:
+        ax = orc.lattice_axes_library(L, N)
+        grid, _ = orc.ann_interpolate(pos, (ax, ax, ax), vec, N)
+        v, m = orc.vm_from_vec_grid(grid, L / N)
+    t["gridding"] = time.perf_counter() - t0
+    out = {}
+    for q in quantities:
+        t1 = time.perf_counter()
+        out[q] = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, L / N, q, flavour=flavour)
+        t["spctrm_" + q] = time.perf_counter() - t1
+    t["total"] = time.perf_counter() - t0
+    return out, t
+
+
+def compare_tables(dev_tabs, ora_tabs):
+    """nsample bit-equal, max relative Psum deviation over the non-empty bins."""
+    eq, worst = True, 0.0
+    for q, ref in ora_tabs.items():
+        got = dev_tabs[q]
+        ref = np.asarray(ref, dtype=np.float64)
+        eq = eq and bool(np.array_equal(got[:, 3], ref[:, 3]))
+        ok = ref[:, 3] > 0
+        if ok.any():
+            worst = max(worst, float(np.max(np.abs(got[ok, 2] - ref[ok, 2]) / np.abs(ref[ok, 2]))))
+    return eq, worst
+
+
+def sample_size(route, N, Np):
+    """Grid of the oracle-checked / CPU-timed sample: same particle density, at most 256^3 (NGP) or
+    128^3 (the NN routes: the oracle's kd-tree search is the slow part)."""
+    Ns = min(N, 256 if route == "ngp" else 128)
+    Nps = max(1000, int(round(Np * (Ns / N) ** 3)))
+    return Ns, Nps
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+# ------------------------------------------------------------------------------------------------
+def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_steps, want_parity, want_cpu):
+    """Times one config; returns the result dict (rank 0 fills the CPU legs)."""
+    import torch
+    import torch.distributed as dist
+    from vpower import device, synth
+    N, Np, off = synth.CONFIGS[cfg]
+    route, quantities, flavour = synth.WORKLOADS[cfg]
+    L = 1.0
+    G = comm.world
+    lognormal = cfg != "C1"      # C1 follows the script, which ignores densities
+
+    # ---- inputs resident in HBM before the timed region (every rank holds the whole particle set) ----
+    if Np >= 50_000_000:
+        dpos, dvel, drho = synth.particles_device(K, synth.BASE_SEED + off, Np, L, lognormal)
+        data = "synthetic (generated on the device: torch Philox, 1e7-particle chunks; preprocessing by vps_preprocess)"
+    else:
+        pos, vel, mass, dens = synth.particles(synth.BASE_SEED + off, Np, L, lognormal)
+        dpos, dvel, drho = K.to_device(pos), K.to_device(vel), K.to_device(dens)
+        del pos, vel, mass, dens
+        data = "synthetic"
+    wl = Workload(K, comm, N, L, route, quantities, flavour, dpos, dvel, drho, unfused=args.unfused)
+    nx = wl.nx
+    nkz, nky, NH = N // 2 // G, N // G, N // 2
+    nfields = wl.fields_per_step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        tabs = wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tabs = wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / steps * 1e3
+    cells = float(N) ** 3 * nfields * world / G   # grid cells x scalar fields per step (whole job; emulation: one rank's share)
+
+    # ---- per-kernel durations (HIP events on the library's stream), untimed extra steps ----
+    K.timing(True)
+    for _ in range(profile_steps):
+        wl.step()
+    tim = K.timing_get()
+    per = {k: np.asarray(K.timing_list(k)) for k in ("fft_z", "fft_y", "fft_x", "deposit", "algebra", "nn_build", "nn_query")}
+    K.timing(False)
+    nst = max(profile_steps, 1)
+    step_kernel_ms = {k: v[1] / nst for k, v in tim.items() if v[0]}
+    # y and x launches alternate main / Nyquist-plane; the main launch is the big one
+    main = {"fft_y": per["fft_y"][0::2], "fft_x": per["fft_x"][0::2], "fft_z": per["fft_z"], "nn_query": per["nn_query"]}
+    Nps = Np / G      # particles inside one rank's slab (uniform positions)
+    # algorithmic HBM bytes of the main launches of ONE step, per kernel family (DESIGN.md "Kernels")
+    step_bytes = {"fft_y": nfields * 16.0 * nx * N * NH, "fft_x": nfields * 8.0 * nkz * N * N}
+    if route == "ngp" and wl.fused:
+        step_bytes["fft_z"] = sum(NCOMP[q] * 8.0 * nx * N * (NH + 1) + 20.0 * Nps for q in quantities)
+    else:
+        wread = 4.0 * nx * N * N if (route == "nn" and "momentum" in quantities) else 0.0
+        step_bytes["fft_z"] = nfields * (4.0 * nx * N * N + wread + 8.0 * nx * N * (NH + 1))
+    if route != "ngp":
+        C_ = 4 if route == "nn" else 3
+        step_bytes["nn_query"] = Np * (12.0 + 4 * C_) + 4.0 * C_ * nx * N * N
+    launches_per_step = {k: max(len(v) // nst, 1) for k, v in main.items() if len(v)}
+    kms = {k: float(np.sum(v)) / nst for k, v in main.items() if len(v)}        # ms per step in main launches
+    dom = max(kms, key=lambda k: kms[k])
+    ach = step_bytes[dom] / (kms[dom] * 1e-3) / 1e9
+    fft_ms = sum(step_kernel_ms.get(k, 0.0) for k in ("fft_z", "fft_y", "fft_x"))
+    fft_bytes = step_bytes["fft_z"] + nfields * (16.0 * nx * N * (NH + 1) + 8.0 * (nkz * N + nky) * N)
+    grid_ms = step_kernel_ms.get("deposit", 0.0) + step_kernel_ms.get("algebra", 0.0) \
+        + step_kernel_ms.get("nn_build", 0.0) + step_kernel_ms.get("nn_query", 0.0)
+    traffic = None
+    tr_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if os.path.exists(tr_path) and world == 1 and G == 1:
+        try:
+            traffic = json.load(open(tr_path)).get(cfg, {}).get(dom)
+        except Exception:
+            traffic = None
+
+    bj = baseline_json()
+    idx = int(cfg[1]) - 1
+    cfg_text = bj["configs"][idx] if idx < len(bj.get("configs", [])) else cfg
+    res = {
+        "ms_per_step": ms_per_step,
+        "value": cells * steps / dt,
+        "config": {"workload": "%s: %s" % (cfg, cfg_text),
+                   "deviation": ("strong-scaled over %d GPU(s) of one node" % world) if cfg in ("C4", "C5") and world != 8 else None,
+                   "grid": N, "particles": Np, "route": route, "quantities": list(quantities),
+                   "scalar_fields_per_step": nfields, "path": wl.describe_path(),
+                   "parallelism": ("x-slab x%d, 1 all-to-all/field (+1 small one for the Nyquist plane)" % world)
+                   if G == world else ("EMULATED rank 0 of %d on one GPU, exchanges skipped (diagnostic)" % G)},
+        "data": data,
+        "particles_per_s": Np / (grid_ms * 1e-3) if grid_ms > 0 else None,
+        "gridding_note": ("bucket sort only: the LDS accumulation of the fused path lives in the fft_z launch"
+                          if (route == "ngp" and wl.fused) else "cell list + NN search (+ algebra)" if route != "ngp"
+                          else "bucket sort + brick accumulate"),
+        "fft_cells_per_s": cells / (fft_ms * 1e-3) if fft_ms > 0 else None,
+        "fft_stage": {"ms_per_step": fft_ms, "algorithmic_GBs": fft_bytes / (fft_ms * 1e-3) / 1e9 if fft_ms else None,
+                      "frac_of_hbm_peak": fft_bytes / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fft_ms else None},
+        "kernel_ms_per_step": step_kernel_ms,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": step_bytes[dom] / launches_per_step[dom],
+                     "avg_launch_ms": kms[dom] / launches_per_step[dom],
+                     "launches_per_step": launches_per_step[dom]},
+        "per_kernel_frac_of_hbm_peak": {k: step_bytes[k] / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS for k in kms},
+    }
+    finite = all(np.isfinite(t[:, 2]).all() and t[:, 3].sum() > 0 for t in tabs.values())
+    if rank == 0 and not os.environ.get("VPS_BENCH_NOCHECK"):      # (timing-only kernel variants produce garbage)
+        assert finite, "non-finite shell sums"
+    # release the big buffers before the sample / the next config
+    del wl, dpos, dvel, drho, tabs
+    K._work.clear()
+    torch.cuda.empty_cache()
+
+    # ---- the same step function on a small sample, against the oracle; CPU baseline on that sample ----
+    if (want_parity or want_cpu) and G == world:
+        Ns, Nps_ = sample_size(route, N, Np)
+        while Ns % (2 * world):
+            Ns *= 2
+        pos, vel, mass, dens = synth.particles(synth.BASE_SEED + 100 + off, Nps_, L, lognormal)
+        swl = Workload(K, comm, Ns, L, route, quantities, flavour, K.to_device(pos), K.to_device(vel),
+                       K.to_device(dens), unfused=args.unfused)
+        dev_tabs = swl.step()
+        del swl
+        if rank == 0:
+            ora_tabs, t1 = oracle_tables(route, quantities, flavour, Ns, L, pos, vel, dens)
+            if want_parity:
+                eq, worst = compare_tables(dev_tabs, ora_tabs)
+                res["parity"] = {"sample": "%d^3 grid, %d particles (the config's particle density), same step() as the timed region, "
+                                           "vs oracle/vps_oracle.py" % (Ns, Nps_),
+                                 "nsample_equal": eq, "psum_max_rel": worst, "psum_rtol": PSUM_RTOL}
+                if not os.environ.get("VPS_BENCH_NOCHECK"):
+                    assert eq, "shell counts differ from the oracle"
+                    assert worst <= PSUM_RTOL, "shell sums differ from the oracle: %.3g" % worst
+            if want_cpu:
+                from oracle import vps_oracle as orc
+                scale = (float(N) / Ns) ** 3
+                unit = "grid cells*components/s"
+                res["cpu_baseline"] = {
+                    "value": Ns ** 3 * nfields / t1["total"], "unit": unit, "cores": 1, "kind": "port",
+                    "sample": "oracle/vps_oracle.py (numpy, float64, 1 thread -- the reference pins FFTW threads=1, interp.py:1382) on "
+                              "%d^3 cells, %d particles = 1/%d of the workload at equal particle density: %s"
+                              % (Ns, Nps_, round(scale), ", ".join("%s %.2fs" % kv for kv in t1.items())),
+                    "seconds": t1["total"],
+                    "extrapolated_seconds_full_size": t1["total"] * scale,
+                    "extrapolation": "by the algorithmic-bytes ratio (N/Ns)^3 (SURVEY.md 8d); not measured",
+                    "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
+                if route != "script":
+                    nthr = os.cpu_count() or 1
+                    orc.set_fft_workers(nthr)
+                    try:
+                        _, t2 = oracle_tables(route, quantities, flavour, Ns, L, pos, vel, dens)
+                    finally:
+                        orc.set_fft_workers(1)
+                    res["cpu_baseline_allcores"] = {
+                        "value": Ns ** 3 * nfields / t2["total"], "unit": unit, "cores": nthr, "kind": "port",
+                        "sample": "same sample; the 3-D transforms threaded over %d cores (scipy.fft workers), gridding and "
+                                  "histograms remain single-threaded numpy: %s"
+                                  % (nthr, ", ".join("%s %.2fs" % kv for kv in t2.items())),
+                        "seconds": t2["total"], "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
+        K._work.clear()
+        torch.cuda.empty_cache()
+    return res
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args, argv))
+
+    if args.dry_run:
+        raise SystemExit(dry_run(args))
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     # VPS_BENCH_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks
     # (ranks share devices, exchanges staged through host memory); the real runs use RCCL.
     backend = os.environ.get("VPS_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -107,8 +489,6 @@ def main():
 
     from vpower import device, synth
     K = device.default_kernels(local)
-    N, Np, off = synth.CONFIGS[args.config]
-    L = 1.0
     comm = device.SlabComm()
     if args.emulate_ranks > 1 and world == 1:
         class _OneOfG(device.SlabComm):
@@ -122,129 +502,35 @@ def main():
             def all_reduce_sum(self, t):
                 return t
         comm = _OneOfG(args.emulate_ranks)
-    pipe = device.PowerPipeline(N, L, kernels=K, comm=comm, flavour="library")
-    nx, x0 = pipe.nx, pipe.x0
 
-    # ---- inputs: generated on the host once, resident in HBM before the timed region ----
-    pos, vel, mass, dens = synth.particles(synth.BASE_SEED + off, Np, L)
-    dpos, dvel, drho = K.to_device(pos), K.to_device(vel), K.to_device(dens)
-    del pos, vel, mass, dens
-    grid = K.empty((3, nx, N, N), torch.float32)
-    psum, nsample = pipe.new_accumulators()      # two views of one buffer: one fill, one D2H copy per step
-    acc_buf = pipe._acc_buf
-    G = comm.world
-    nkz, nky = N // 2 // G, N // G
-
-    fused = K.fused_supported(N, device.VELOCITY) and not args.unfused
-    if fused:
-        spec3 = K.empty((3, N // 2, N, nx), torch.complex64)
-        nyq3 = K.empty((3, N, nx), torch.complex64)
-
-    def step():
-        acc_buf.zero_()
-        if fused:
-            # deposit + v = rho v / rho + z pass in one kernel (pencil buckets), then the y passes
-            K.deposit_fft_zy(dpos, dvel, drho, N, L, x0, nx, device.VELOCITY, spec=spec3, nyq=nyq3)
-        else:
-            K.deposit_field(dpos, dvel, drho, N, L, x0, nx, device.VELOCITY, out=grid)
-        if fused:
-            pipe.accumulate_spectra(spec3, nyq3, psum, nsample)     # 3 x (all-to-all, x pass + binning)
-        else:
-            pipe.accumulate([grid[0], grid[1], grid[2]], psum, nsample)   # 3 x (z/y passes, all-to-all, x pass)
-        tab = pipe.finish(psum, nsample)     # all-reduce, D2H, table
-        tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2
-        return tab
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        tab = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tab = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-    cells = float(N) ** 3 * 3 * world / comm.world   # grid cells x components per step (whole job; emulation: one rank's share)
-
-    # ---- per-kernel durations (HIP events on the library's stream), untimed extra steps ----
-    K.timing(True)
-    for _ in range(args.profile_steps):
-        step()
-    tim = K.timing_get()
-    per = {k: K.timing_list(k) for k in ("fft_z", "fft_y", "fft_x", "deposit", "algebra")}
-    K.timing(False)
-    nst = args.profile_steps
-    # y and x launches alternate main / Nyquist-plane; the main launch is the big one
-    main_y, main_x = per["fft_y"][0::2], per["fft_x"][0::2]
-    NH = N // 2
-    mean = lambda v: float(np.mean(v)) if len(v) else 0.0
-    if fused:
-        # one pencil launch per step: the bucket records in (20 B per particle, once: the later rounds re-read
-        # them from registers / L2), three z-transformed fields out
-        z_bytes = 3 * 8.0 * nx * N * (NH + 1) + 20.0 * Np / G
-        z_per_field = z_bytes / 3
-    else:
-        z_bytes = 4.0 * nx * N * N + 8.0 * nx * N * (NH + 1)
-        z_per_field = z_bytes
-    alg_bytes = {   # algorithmic HBM bytes per main launch (DESIGN.md "Kernels")
-        "fft_z": z_bytes,
-        "fft_y": 16.0 * nx * N * NH,
-        "fft_x": 3 * 8.0 * nkz * N * N,   # one launch transforms and bins the three components
-    }
-    avg_ms = {"fft_z": mean(per["fft_z"]), "fft_y": mean(main_y), "fft_x": mean(main_x),
-              # gridding stage: rank+scan+scatter ("deposit") and, unfused, brick accumulate+write ("algebra");
-              # fused, the accumulation lives inside the z-pass launch
-              "deposit": mean(per["deposit"]) + mean(per["algebra"])}
-    step_kernel_ms = {k: v[1] / nst for k, v in tim.items() if v[0]}
-    dom = max(("fft_z", "fft_y", "fft_x"), key=lambda k: step_kernel_ms.get(k, 0.0))
-    ach = alg_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
-    fft_ms = sum(step_kernel_ms.get(k, 0.0) for k in ("fft_z", "fft_y", "fft_x"))
-    fft_bytes = 3 * (z_per_field + 16.0 * nx * N * (NH + 1) + 8.0 * (nkz * N + nky) * N)
-    traffic = None
-    tr_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tr_path) and args.config == "C2" and world == 1 and comm.world == 1:
-        try:
-            traffic = json.load(open(tr_path)).get("fft_z_fused" if (dom == "fft_z" and fused) else dom)
-        except Exception:
-            traffic = None
-
+    cfg = args.config
+    if cfg not in synth.CONFIGS:
+        raise SystemExit("unknown config %s" % cfg)
+    single = world == 1 and comm.world == 1
+    res = run_config(args, cfg, K, comm, world, rank, backend, args.steps, args.warmup, args.profile_steps,
+                     want_parity=not args.no_parity and comm.world == world,
+                     want_cpu=single and not args.no_cpu_baseline)
     out = {
-        "metric": baseline_metric(),
-        "value_definition": "N^3 x components / step time: the whole path particles -> P(k) table; stage rates in "
-                            "particles_per_s and fft_cells_per_s, HBM fraction in roofline",
-        "value": cells * args.steps / dt,
-        "unit": "grid cells*components/s",
+        "metric": baseline_json()["metric"],
+        "value_definition": "N^3 x scalar fields / step time: the whole path particles -> P(k) tables of the config's "
+                            "quantities; stage rates in particles_per_s and fft_cells_per_s, HBM fraction in roofline",
+        "value": res.pop("value"), "unit": "grid cells*components/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d^3 grid, %d particles, velocity P(k), NGP deposit, library binning"
-                               % (args.config, N, Np), "grid": N, "particles": Np,
-                   "path": "fused deposit+z pass (pencil buckets)" if fused else "deposit -> grid -> z pass",
-                   "parallelism": ("x-slab x%d, 1 all-to-all/field" % world) if comm.world == world else
-                                  ("EMULATED rank 0 of %d on one GPU, exchanges skipped (diagnostic)" % comm.world)},
-        "particles_per_s": Np / (avg_ms["deposit"] * 1e-3) if avg_ms["deposit"] > 0 else None,
-        "fft_cells_per_s": cells / (fft_ms * 1e-3) / 1.0 if fft_ms > 0 else None,
-        "fft_stage": {"ms_per_step": fft_ms, "algorithmic_GBs": fft_bytes / (fft_ms * 1e-3) / 1e9 if fft_ms else None,
-                      "frac_of_hbm_peak": fft_bytes / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fft_ms else None},
-        "kernel_ms_per_step": step_kernel_ms,
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": avg_ms[dom]},
+        "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": res.pop("data"),
     }
-    if rank == 0 and world == 1 and comm.world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+    out.update(res)
+    if single and cfg == "C4" and not args.no_other_configs:
+        # the two single-GPU configs of BASELINE.json, short runs, reported beside the headline
+        other = {}
+        for c in ("C2", "C3"):
+            r = run_config(args, c, K, comm, world, rank, backend, steps=5, warmup=2, profile_steps=2,
+                           want_parity=not args.no_parity, want_cpu=False)
+            other[c] = {k: r[k] for k in ("ms_per_step", "value", "config", "particles_per_s", "fft_cells_per_s", "fft_stage",
+                                          "kernel_ms_per_step", "roofline", "per_kernel_frac_of_hbm_peak", "parity") if k in r}
+            other[c]["steps"] = 5
+        out["other_configs"] = other
     if rank == 0:
-        if not os.environ.get("VPS_BENCH_NOCHECK"):      # (timing-only kernel variants produce garbage)
-            assert np.isfinite(tab[:, 2]).all() and tab[:, 3].sum() > 0
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

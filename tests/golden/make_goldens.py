@@ -11,8 +11,10 @@ mpi4py, annoy, h5py, pyann, voxelize, memory_profiler) are replaced by small
   annoy   -> exact NN (float32 coordinates, float64 distances)  [Annoy's own
              approximate answers are parity-unpinned, SURVEY.md section 8c]
   pyann   -> exact NN, 1-based indices as pyann returns them
-  mpi4py  -> one-rank communicator
-  h5py    -> dict-backed File
+  mpi4py  -> one-rank communicator; for the multi-rank fixtures a thread-backed one
+             (every emulated rank is a thread calling the reference's main(); allgather /
+             Reduce / Barrier meet at a threading.Barrier, gather order = rank order)
+  h5py    -> dict-backed File (datasets hand out copies, as reading a file does)
 Only inputs-by-seed and the reference's OUTPUTS are written (npz, no pickles);
 no reference source text is stored.
 """
@@ -80,11 +82,43 @@ def install_shims(h5_store):
     MPI = types.ModuleType("mpi4py.MPI")
 
     class Comm:
-        def Get_rank(self): return 0
-        def Get_size(self): return 1
-        def Barrier(self): pass
-        def allgather(self, x): return [x]
-        def Reduce(self, sendbuf, recvbuf, op=None, root=0): recvbuf[...] = sendbuf
+        """One rank, or `size` ranks emulated by threads (set_world(size); each thread calls
+        bind(rank) first).  Semantics of the three collectives the reference uses
+        (scripts/parallel_optimized.py:254, 365-368, 455-456)."""
+        def __init__(self):
+            self.set_world(1)
+
+        def set_world(self, size):
+            import threading
+            self.size = size
+            self.local = threading.local()
+            self.barrier = threading.Barrier(size)
+            self.slots = [None] * size
+
+        def bind(self, rank): self.local.rank = rank
+        def Get_rank(self): return getattr(self.local, "rank", 0)
+        def Get_size(self): return self.size
+        def Barrier(self): self.barrier.wait()
+
+        def allgather(self, x):
+            if self.size == 1:
+                return [x]
+            self.slots[self.Get_rank()] = x
+            self.barrier.wait()
+            out = list(self.slots)
+            self.barrier.wait()
+            return out
+
+        def Reduce(self, sendbuf, recvbuf, op=None, root=0):
+            if self.size == 1:
+                recvbuf[...] = sendbuf
+                return
+            parts = self.allgather(np.array(sendbuf, copy=True))
+            if self.Get_rank() == root:
+                acc = parts[0].copy()
+                for q in parts[1:]:          # rank order, in the send dtype (MPI_SUM on float32 buffers)
+                    acc = acc + q
+                recvbuf[...] = acc
     MPI.COMM_WORLD = Comm()
     MPI.SUM = "sum"
     mpi4py.MPI = MPI
@@ -112,13 +146,17 @@ def install_shims(h5_store):
     # h5py -----------------------------------------------------------------
     h5py = types.ModuleType("h5py")
 
+    class Dataset:
+        def __init__(self, a): self.a = a
+        def __getitem__(self, k): return np.array(self.a[k], copy=True)
+
     class File:
         def __init__(self, name, mode="r"): self.store = h5_store
         def __getitem__(self, key):
             node = self.store
             for part in key.split("/"):
                 node = node[part]
-            return node
+            return Dataset(node) if isinstance(node, np.ndarray) else node
         def close(self): pass
     h5py.File = File
     sys.modules["h5py"] = h5py
@@ -293,6 +331,45 @@ def main():
         pk = np.loadtxt(os.path.join(outdir, "Pk.txt"))
         np.savez_compressed(os.path.join(HERE, f"script_{tag}.npz"),
                             seed=seed, N=N, Np=Np, L=L, Pk=pk)
+
+    # (v-b) script main() on 8 emulated MPI ranks: the fold + allgather + Reduce path
+    # (scripts/parallel_optimized.py:322-391, 455-456) on the SAME particles as (v).
+    #   n16_m2: -N 16 -M 8  -> 8 ranks x 8^3 boxes, 1 loop,  2-fold
+    #   n16_m4: -N 16 -M 4  -> 8 ranks x 4^3 boxes, 8 loops, 4-fold (Pk.txt accumulates over the loops, :472-485)
+    #   n32_m2: -N 32 -M 16 -> 8 ranks x 16^3 boxes, 1 loop, 2-fold
+    import threading
+    comm = sys.modules["mpi4py.MPI"].COMM_WORLD
+    for tag, N, M, Np, seed in (("n16_m2", 16, 8, 3000, 201), ("n16_m4", 16, 4, 3000, 201), ("n32_m2", 32, 16, 20000, 202)):
+        L = 1
+        pos, vel, mass, dens = synth(seed, Np, float(L), lognormal_density=False)
+        h5_store.clear()
+        h5_store["PartType0"] = {"Coordinates": pos.copy(), "Masses": mass.copy(), "Velocities": vel.copy()}
+        outdir = tempfile.mkdtemp()
+        script.SNAPSHOT, script.SAVEDIR = snap, outdir
+        script.NTOT, script.MAXNBOX, script.LTOT = N, M, L
+        script.NBUFFER, script.FORCE = 5000, True
+        plan = script.planner(N, L, M, 8)
+        comm.set_world(8)
+        errors = []
+
+        def run_rank(r):
+            comm.bind(r)
+            try:
+                assert script.main() == 0
+            except BaseException as e:      # noqa: BLE001  (a dead rank must not leave the others at the barrier)
+                errors.append((r, repr(e)))
+                comm.barrier.abort()
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+            threads = [threading.Thread(target=run_rank, args=(r,)) for r in range(8)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        comm.set_world(1)
+        assert not errors, errors
+        pk = np.loadtxt(os.path.join(outdir, "Pk.txt"))
+        np.savez_compressed(os.path.join(HERE, f"script_8rank_{tag}.npz"), seed=seed, N=N, M=M, Np=Np, L=L, ranks=8,
+                            plan=np.array(plan, dtype=np.float64), Pk=pk)
 
     # (vi) FFT power known answers through the reference functions -----------
     rng = np.random.default_rng(7)
