@@ -93,6 +93,16 @@ int vps_preprocess(vps_ctx* ctx, void* pos_dev, int pos_is_f64, float* vel_dev,
                    const float* mass_dev, int64_t np, int shift_to_origin,
                    int remove_bulk_velocity, double* min_out_host, double* bulk_out_host);
 
+/* ---- conservation diagnostics -------------------------------------------- */
+/* out_host[5] = sum m, sum m vx, sum m vy, sum m vz, sum m (vx^2+vy^2+vz^2), accumulated in float64:
+ * the totals behind total_mass / total_momentum / total_kinetic_energy (x 0.5 on the host) of
+ * GasParticles (vpower/interp.py:424-450) and BoxField (interp.py:639-666), i.e. check_conservation
+ * (interp.py:1269-1319).  Component c of element i is v_dev[i*v_elem_stride + c*v_comp_stride]:
+ * particles (vel [np][3]): strides 3, 1; a gridded field (chans [4][ncell] = vx,vy,vz,mass): strides 1, ncell
+ * with mass_dev = chans + 3*ncell.  Blocks. */
+int vps_totals(vps_ctx* ctx, const float* v_dev, int64_t v_elem_stride, int64_t v_comp_stride,
+               const float* mass_dev, int64_t n, double out_host[5]);
+
 /* ---- stage A1: nearest-grid-point deposition ---------------------------- */
 /* Replaces deposit_to_grid (vpower/interp.py:996-1015).
  * Cell index per axis = int((pos // Lcell) % N) evaluated with numpy's

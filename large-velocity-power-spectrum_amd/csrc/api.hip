@@ -77,7 +77,7 @@ int vps_create(vps_ctx** out, int device_id) {
 
 int vps_destroy(vps_ctx* ctx) {
   if (!ctx) return VPS_OK;
-  (void)hipSetDevice(ctx->device);
+  vps_device_guard guard(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   vps_fft_free_tables(ctx);
   if (ctx->d_k2) (void)hipFree(ctx->d_k2);
@@ -96,19 +96,20 @@ int vps_destroy(vps_ctx* ctx) {
 const char* vps_last_error(const vps_ctx* ctx) { return ctx ? ctx->err : g_last_error; }
 
 int vps_set_stream(vps_ctx* ctx, void* hip_stream) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
   return VPS_OK;
 }
 
 int vps_sync(vps_ctx* ctx) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return VPS_OK;
 }
 
 int vps_device_info(vps_ctx* ctx, int64_t out[4]) {
-  if (!ctx || !out) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
+  if (!out) return VPS_ERR_ARG;
   hipDeviceProp_t prop;
   VPS_HIP_CHECK(ctx, hipGetDeviceProperties(&prop, ctx->device));
   out[0] = prop.multiProcessorCount;
@@ -119,7 +120,8 @@ int vps_device_info(vps_ctx* ctx, int64_t out[4]) {
 }
 
 int vps_malloc(vps_ctx* ctx, void** dev, size_t bytes) {
-  if (!ctx || !dev) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
+  if (!dev) return VPS_ERR_ARG;
   *dev = nullptr;
   hipError_t e = hipMalloc(dev, bytes ? bytes : 1);
   if (e == hipErrorOutOfMemory) return vps_fail(ctx, VPS_ERR_NOMEM, "hipMalloc(%zu) out of memory", bytes);
@@ -128,38 +130,41 @@ int vps_malloc(vps_ctx* ctx, void** dev, size_t bytes) {
 }
 
 int vps_free(vps_ctx* ctx, void* dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (dev) VPS_HIP_CHECK(ctx, hipFree(dev));
   return VPS_OK;
 }
 
 int vps_memset(vps_ctx* ctx, void* dev, int value, size_t bytes) {
-  if (!ctx || (!dev && bytes)) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
+  if (!dev && bytes) return VPS_ERR_ARG;
   if (bytes) VPS_HIP_CHECK(ctx, hipMemsetAsync(dev, value, bytes, ctx->stream));
   return VPS_OK;
 }
 
 int vps_memcpy_h2d(vps_ctx* ctx, void* dev, const void* host, size_t bytes) {
-  if (!ctx || ((!dev || !host) && bytes)) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
+  if ((!dev || !host) && bytes) return VPS_ERR_ARG;
   if (bytes) VPS_HIP_CHECK(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
   return VPS_OK;
 }
 
 int vps_memcpy_d2h(vps_ctx* ctx, void* host, const void* dev, size_t bytes) {
-  if (!ctx || ((!dev || !host) && bytes)) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
+  if ((!dev || !host) && bytes) return VPS_ERR_ARG;
   if (bytes) VPS_HIP_CHECK(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
   VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return VPS_OK;
 }
 
 int vps_timing_enable(vps_ctx* ctx, int on) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   ctx->timing = on != 0;
   return VPS_OK;
 }
 
 int vps_timing_reset(vps_ctx* ctx) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   for (auto& l : ctx->launches) {
     ctx->event_pool.push_back(l.start);
@@ -170,7 +175,8 @@ int vps_timing_reset(vps_ctx* ctx) {
 }
 
 int vps_timing_get(vps_ctx* ctx, int kind, int64_t* launches, double* total_ms) {
-  if (!ctx || kind < 0 || kind >= VPS_K_COUNT) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
+  if (kind < 0 || kind >= VPS_K_COUNT) return VPS_ERR_ARG;
   VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   int64_t n = 0;
   double ms = 0.0;
@@ -187,7 +193,8 @@ int vps_timing_get(vps_ctx* ctx, int kind, int64_t* launches, double* total_ms) 
 }
 
 int vps_timing_list(vps_ctx* ctx, int kind, double* ms_out, int64_t cap, int64_t* n_out) {
-  if (!ctx || kind < 0 || kind >= VPS_K_COUNT || cap < 0 || (cap && !ms_out)) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
+  if (kind < 0 || kind >= VPS_K_COUNT || cap < 0 || (cap && !ms_out)) return VPS_ERR_ARG;
   VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   int64_t n = 0;
   for (auto& l : ctx->launches) {
@@ -205,7 +212,7 @@ int vps_timing_list(vps_ctx* ctx, int kind, double* ms_out, int64_t cap, int64_t
 
 int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const double* thr_host,
                     int nbins, double edge0, double inv_spacing) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (N < 2 || nbins < 1 || !k2_axis_host || !thr_host)
     return vps_fail(ctx, VPS_ERR_ARG, "vps_set_binning: bad arguments (N=%d nbins=%d)", N, nbins);
   if (nbins > 8192) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "nbins=%d > 8192", nbins);

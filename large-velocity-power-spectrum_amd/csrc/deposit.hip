@@ -899,7 +899,7 @@ extern "C" {
 
 int vps_cell_index(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, int64_t np, int N, double Lbox,
                    int32_t* cell_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (np < 0 || N < 1 || !(Lbox > 0)) return vps_fail(ctx, VPS_ERR_ARG, "vps_cell_index: bad np/N/Lbox");
   if (np == 0) return VPS_OK;
   if (!pos_dev || !cell_dev) return vps_fail(ctx, VPS_ERR_ARG, "vps_cell_index: null buffer");
@@ -928,7 +928,7 @@ size_t vps_deposit_workspace_bytes(int64_t np, int C, int N, int nx) {
 int vps_deposit_ngp(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* payload_dev,
                     int64_t np, int C, int N, double Lbox, int x0, int nx, float* grid_dev,
                     void* work_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   int rc = check_deposit_args(ctx, "vps_deposit_ngp", np, N, Lbox, x0, nx);
   if (rc) return rc;
   if (!grid_dev || !work_dev || (np > 0 && (!pos_dev || !payload_dev)))
@@ -950,7 +950,7 @@ int vps_deposit_ngp(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const flo
 int vps_deposit_field(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
                       const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx, int quantity,
                       int flags, float* fields_dev, void* work_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   int rc = check_deposit_args(ctx, "vps_deposit_field", np, N, Lbox, x0, nx);
   if (rc) return rc;
   if (quantity < 0 || quantity > 3) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_field: quantity %d", quantity);
@@ -979,7 +979,7 @@ size_t vps_deposit_fft_zy_workspace_bytes(int64_t np, int N, int nx) {
 int vps_deposit_fft_zy(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
                        const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx, int quantity,
                        int flags, void* spec_dev, void* nyq_dev, void* work_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   int rc = check_deposit_args(ctx, "vps_deposit_fft_zy", np, N, Lbox, x0, nx);
   if (rc) return rc;
   if (!vps_deposit_fft_zy_supported(ctx, N, quantity))
@@ -1008,7 +1008,7 @@ int vps_deposit_fft_zy(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const 
 
 int vps_density_velocity_vector(vps_ctx* ctx, const float* vel_dev, const float* rho_dev, int64_t np,
                                 float* out_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (np < 0) return vps_fail(ctx, VPS_ERR_ARG, "vps_density_velocity_vector: np < 0");
   if (np == 0) return VPS_OK;
   if (!vel_dev || !rho_dev || !out_dev) return vps_fail(ctx, VPS_ERR_ARG, "vps_density_velocity_vector: null buffer");
@@ -1032,7 +1032,7 @@ int vps_field_algebra(vps_ctx* ctx, int quantity, int flags, double Lcell, float
 
 int vps_field_algebra_out(vps_ctx* ctx, int quantity, int flags, double Lcell, const float* chans_dev,
                           int64_t ncell, float* out_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (quantity < 0 || quantity > 3) return vps_fail(ctx, VPS_ERR_ARG, "vps_field_algebra: quantity %d", quantity);
   if (ncell < 0 || (ncell & 3)) return vps_fail(ctx, VPS_ERR_ARG, "vps_field_algebra: ncell must be a multiple of 4");
   if (ncell == 0) return VPS_OK;

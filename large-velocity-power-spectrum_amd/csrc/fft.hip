@@ -1534,7 +1534,7 @@ int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev, void* spec_d
 
 int vps_fft_zy_weighted(vps_ctx* ctx, int N, int nx, const float* field_dev, const float* weight_dev,
                         void* spec_dev, void* nyq_dev, void* work_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   if (nx < 1 || nx > N) return vps_fail(ctx, VPS_ERR_ARG, "nx=%d out of range", nx);
   if (!field_dev || !spec_dev || !nyq_dev || !work_dev) return vps_fail(ctx, VPS_ERR_ARG, "null buffer");
@@ -1654,7 +1654,7 @@ extern "C" {
 static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const void* in_dev,
                       const void* in1_dev, const void* in2_dev, int ncomp, int nseg, int64_t seg_stride,
                       int mode, double* psum_dev, unsigned long long* nsample_dev, void* out_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   if (nlines < 0 || !in_dev) return vps_fail(ctx, VPS_ERR_ARG, "bad line count / null input");
   if (nseg < 1 || N % nseg) return vps_fail(ctx, VPS_ERR_ARG, "nseg=%d must divide N", nseg);
@@ -1720,7 +1720,7 @@ int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const
 int vps_fft_x_bin(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const void* const* in_devs,
                   int ncomp, int nseg, int64_t seg_stride, int count, double* psum_dev,
                   unsigned long long* nsample_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (ncomp < 1 || ncomp > 3 || !in_devs) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_x_bin: ncomp must be 1..3");
   for (int c = 0; c < ncomp; ++c)
     if (!in_devs[c]) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_x_bin: null component %d", c);
@@ -1730,7 +1730,7 @@ int vps_fft_x_bin(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, c
 
 int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, double* psum_dev,
                   unsigned long long* nsample_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   const size_t half = vps_fft_workspace_bytes(N, N);
   char* w = reinterpret_cast<char*>(work_dev);
@@ -1744,7 +1744,7 @@ int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, d
 }
 
 int vps_rfft3(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, void* out_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   const size_t half = vps_fft_workspace_bytes(N, N);
   char* w = reinterpret_cast<char*>(work_dev);
@@ -1759,7 +1759,7 @@ int vps_rfft3(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, void*
 }
 
 int vps_power_grid(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, float* power_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   const size_t half = vps_fft_workspace_bytes(N, N);
   char* w = reinterpret_cast<char*>(work_dev);

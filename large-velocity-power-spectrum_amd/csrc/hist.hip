@@ -63,7 +63,7 @@ extern "C" {
 
 int vps_pair_k(vps_ctx* ctx, int N, const double* kx_host, const double* ky_host,
                const double* kz_host, double* out_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (N < 1 || !kx_host || !ky_host || !kz_host || !out_dev) return vps_fail(ctx, VPS_ERR_ARG, "vps_pair_k: bad arguments");
   const size_t one = (size_t)N * sizeof(double);
   const size_t need = 3 * one;
@@ -92,7 +92,7 @@ int vps_pair_k(vps_ctx* ctx, int N, const double* kx_host, const double* ky_host
 int vps_hist_pairs(vps_ctx* ctx, const double* k_dev, const double* w_dev, int64_t n,
                    const double* edges_host, int nbins, double* psum_dev,
                    unsigned long long* nsample_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (n < 0 || nbins < 1 || nbins > 8192 || !edges_host || !psum_dev || !nsample_dev)
     return vps_fail(ctx, VPS_ERR_ARG, "vps_hist_pairs: bad arguments");
   for (int i = 0; i < nbins; ++i)

@@ -485,7 +485,7 @@ int vps_nn_resample(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const flo
                     int64_t np, int C, const double* qx_host, int nqx, const double* qy_host, int nqy,
                     const double* qz_host, int nqz, int x0, int nx, float* out_dev,
                     int32_t* nn_idx_dev, void* work_dev) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (np < 1) return vps_fail(ctx, VPS_ERR_ARG, "vps_nn_resample: need at least one particle");
   if (np > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_nn_resample: np exceeds int32 indices");
   if (nqx < 1 || nqy < 1 || nqz < 1 || !qx_host || !qy_host || !qz_host)

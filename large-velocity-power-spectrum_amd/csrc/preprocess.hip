@@ -126,12 +126,60 @@ int prep_run(vps_ctx* ctx, F* pos, float* vel, const float* mass, int64_t np, in
   return VPS_OK;
 }
 
+// sum m, sum m v_c, sum m |v|^2 in float64: the totals behind check_conservation (interp.py:1269-1319)
+__global__ void __launch_bounds__(256)
+    totals_kernel(const float* __restrict__ v, long long vs, long long vc, const float* __restrict__ mass,
+                  long long n, double* __restrict__ out) {
+  double w[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double m = (double)mass[i];
+    const double vx = (double)v[i * vs], vy = (double)v[i * vs + vc], vz = (double)v[i * vs + 2 * vc];
+    w[0] += m;
+    w[1] += m * vx;
+    w[2] += m * vy;
+    w[3] += m * vz;
+    w[4] += m * ((vx * vx + vy * vy) + vz * vz);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 5; ++a) w[a] += __shfl_down(w[a], off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 5; ++a) atomicAdd(&out[a], w[a]);
+  }
+}
+
 }  // namespace
+
+extern "C" int vps_totals(vps_ctx* ctx, const float* v_dev, int64_t v_elem_stride, int64_t v_comp_stride,
+                          const float* mass_dev, int64_t n, double out_host[5]) {
+  VPS_ENTER(ctx);
+  if (n < 0 || !out_host || (n > 0 && (!v_dev || !mass_dev))) return vps_fail(ctx, VPS_ERR_ARG, "vps_totals: bad arguments");
+  for (int a = 0; a < 5; ++a) out_host[a] = 0.0;
+  if (n == 0) return VPS_OK;
+  double* d = nullptr;
+  VPS_HIP_CHECK(ctx, hipMalloc(&d, 5 * sizeof(double)));
+  hipError_t e = hipMemsetAsync(d, 0, 5 * sizeof(double), ctx->stream);
+  if (e == hipSuccess) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > (long long)ctx->num_cu * 8) blocks = (long long)ctx->num_cu * 8;
+    vps_launch_timer tm(ctx, VPS_K_MISC);
+    hipLaunchKernelGGL(totals_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, v_dev, (long long)v_elem_stride,
+                       (long long)v_comp_stride, mass_dev, (long long)n, d);
+  }
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out_host, d, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  VPS_HIP_CHECK(ctx, e);
+  return VPS_OK;
+}
 
 extern "C" int vps_preprocess(vps_ctx* ctx, void* pos_dev, int pos_is_f64, float* vel_dev, const float* mass_dev,
                               int64_t np, int shift_to_origin, int remove_bulk_velocity, double* min_out_host,
                               double* bulk_out_host) {
-  if (!ctx) return VPS_ERR_ARG;
+  VPS_ENTER(ctx);
   if (np < 1) return vps_fail(ctx, VPS_ERR_ARG, "vps_preprocess: need at least one particle");
   if ((np + 255) / 256 > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_preprocess: np too large for one launch");
   if (!pos_dev || (remove_bulk_velocity && (!vel_dev || !mass_dev)))

@@ -53,6 +53,23 @@ struct vps_ctx {
 
 int vps_fail(vps_ctx* ctx, int code, const char* fmt, ...);
 
+// Every entry point of the C ABI runs with the context's device current and restores the caller's
+// on return: the library allocates (tables, partial sums, lattice axes) and launches on streams
+// that belong to ctx->device, whatever device the calling thread had selected.
+struct vps_device_guard {
+  int prev = -1;
+  explicit vps_device_guard(const vps_ctx* ctx) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != ctx->device && hipSetDevice(ctx->device) == hipSuccess) prev = cur;
+  }
+  ~vps_device_guard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+#define VPS_ENTER(ctx)                 \
+  if (!(ctx)) return VPS_ERR_ARG;      \
+  vps_device_guard vps_guard_(ctx)
+
 #define VPS_HIP_CHECK(ctx, expr)                                                   \
   do {                                                                             \
     hipError_t _e = (expr);                                                        \

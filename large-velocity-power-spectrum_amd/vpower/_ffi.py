@@ -40,6 +40,7 @@ SYMBOLS = (
     ("vps_timing_get", C.c_int, (_vp, C.c_int, C.POINTER(_i64), _dp)),
     ("vps_timing_list", C.c_int, (_vp, C.c_int, _dp, _i64, C.POINTER(_i64))),
     ("vps_preprocess", C.c_int, (_vp, _vp, C.c_int, _vp, _vp, _i64, C.c_int, C.c_int, _dp, _dp)),
+    ("vps_totals", C.c_int, (_vp, _vp, _i64, _i64, _vp, _i64, _dp)),
     ("vps_cell_index", C.c_int, (_vp, _vp, C.c_int, _i64, C.c_int, C.c_double, _vp)),
     ("vps_deposit_workspace_bytes", C.c_size_t, (_i64, C.c_int, C.c_int, C.c_int)),
     ("vps_deposit_ngp", C.c_int, (_vp, _vp, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_double,
@@ -86,14 +87,27 @@ class VpsError(RuntimeError):
 
 def build(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into vpower/libvps_hip.so (in tree)."""
+    import glob
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "vps_internal.h"), os.path.join(REPO_ROOT, "include", "vps_hip.h")]
-    if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
-            return LIB_PATH
+    # every header is a dependency of every unit (scan.h, vps_internal.h, the ABI header, ...)
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(REPO_ROOT, "include", "*.h")))
+    deps = srcs + headers
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
+    # the flags are part of what an object was built from: a change rebuilds everything
+    stamp_path = os.path.join(objdir, "flags.stamp")
+    stamp = " ".join((hipcc,) + HIPCC_FLAGS + tuple(SOURCES)) + " parts=%d" % FFT_PARTS
+    try:
+        same_flags = open(stamp_path).read() == stamp
+    except OSError:
+        same_flags = False
+    if not same_flags:
+        force = True
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    newest_header = max(os.path.getmtime(h) for h in headers)
     objs, procs = [], []
     units = []
     for s in srcs:
@@ -105,8 +119,7 @@ def build(force=False, verbose=False):
             units.append((s, os.path.join(objdir, stem + ".o"), []))
     for s, o, extra in units:
         objs.append(o)
-        if not force and os.path.exists(o) and os.path.getmtime(o) >= max(
-                os.path.getmtime(s), os.path.getmtime(deps[-1]), os.path.getmtime(deps[-2])):
+        if not force and os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), newest_header):
             continue
         cmd = [hipcc, *HIPCC_FLAGS, *extra, "-c", s, "-o", o]
         if verbose:
@@ -120,6 +133,8 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise VpsError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode(errors="replace")))
+    with open(stamp_path, "w") as f:
+        f.write(stamp)
     return LIB_PATH
 
 

@@ -209,6 +209,22 @@ class HipKernels:
                                           1 if remove_bulk_velocity else 0, _ffi.as_dp(mn), _ffi.as_dp(bv)))
         return mn, bv
 
+    def totals(self, v, mass, elem_stride, comp_stride, n):
+        """float64 [sum m, sum m vx, sum m vy, sum m vz, sum m |v|^2] (vps_totals)."""
+        self._stream()
+        out = np.zeros(5)
+        self._chk(self.lib.vps_totals(self.ctx, self._ptr(v, torch.float32), int(elem_stride), int(comp_stride),
+                                      self._ptr(mass, torch.float32), int(n), _ffi.as_dp(out)))
+        return out
+
+    def particle_totals(self, vel, mass):
+        return self.totals(vel, mass, 3, 1, vel.shape[0])
+
+    def field_totals(self, chans):
+        """chans [4, ...] = vx, vy, vz, mass of a gridded field."""
+        n = chans[0].numel()
+        return self.totals(chans, chans[3], 1, n, n)
+
     @staticmethod
     def _pos_kind(pos):
         if pos.dtype == torch.float32:

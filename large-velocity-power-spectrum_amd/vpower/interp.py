@@ -305,20 +305,32 @@ class BoxField:
         return PowerSpectrum(pipe.spectrum(fields))
 
     # -- diagnostics (interp.py:639-666) ----------------------------------------------
+    def _totals(self):
+        """[sum m, sum m vx, sum m vy, sum m vz, sum m |v|^2]: one float64 device reduction over the
+        four channels while the field lives in HBM (no download); numpy if it was built from / has been
+        replaced by host arrays."""
+        self._materialise()
+        if self._chans is not None:
+            return _kernels().field_totals(self._chans)
+        m, vx, vy, vz = self.mass, self.vx, self.vy, self.vz
+        return np.array([np.sum(m), np.sum(m * vx), np.sum(m * vy), np.sum(m * vz),
+                         np.sum(m * (vx ** 2 + vy ** 2 + vz ** 2))], dtype=np.float64)
+
     def mean_kinetic_energy(self) -> float:
-        return 0.5 * np.mean(self.mass * (self.vx ** 2 + self.vy ** 2 + self.vz ** 2))
+        return 0.5 * self._totals()[4] / float(self.Nsize) ** 3
 
     def total_kinetic_energy(self) -> float:
-        return 0.5 * np.sum(self.mass * (self.vx ** 2 + self.vy ** 2 + self.vz ** 2))
+        return 0.5 * self._totals()[4]
 
     def total_mass(self) -> float:
-        return np.sum(self.mass)
+        return self._totals()[0]
 
     def specific_kinetic_energy(self) -> float:
-        return self.total_kinetic_energy() / self.total_mass()
+        t = self._totals()
+        return 0.5 * t[4] / t[0]
 
     def total_momentum(self) -> np.ndarray:
-        return np.array([np.sum(self.mass * self.vx), np.sum(self.mass * self.vy), np.sum(self.mass * self.vz)])
+        return self._totals()[1:4].copy()
 
 
 def check_conservation(gasParticles, boxField) -> tuple:

@@ -201,3 +201,26 @@ def test_lattice_recovery_from_grid_coords():
     assert np.array_equal(ax, orc.lattice_axes_library(1.0, 8)) and np.array_equal(ay, ax) and np.array_equal(az, ax)
     with pytest.raises(Exception):
         interp._axes_of_lattice(np.random.default_rng(1).permutation(q), 8)
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher spawns N ranks (torch.distributed.run child,
+    gloo here) before importing torch, relays rank 0's line, and fails when a rank fails."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["rank_sum"] == 1.0
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run", "--dry-run-fail-rank", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
+    # under a launcher (WORLD_SIZE set) it must not spawn again, and a wrong --gpus is an error
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=env2, capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 2
