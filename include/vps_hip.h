@@ -57,7 +57,7 @@ int vps_destroy(vps_ctx* ctx);
 const char* vps_last_error(const vps_ctx* ctx);   /* ctx may be NULL: global slot */
 int vps_set_stream(vps_ctx* ctx, void* hip_stream);
 int vps_sync(vps_ctx* ctx);
-int vps_version(void);                            /* ABI version, currently 1       */
+int vps_version(void);                            /* ABI version, currently 2       */
 /* device facts for the host side: out[0]=CUs, out[1]=LDS bytes/CU, out[2]=wave size,
  * out[3]=HBM bytes total (MiB) */
 int vps_device_info(vps_ctx* ctx, int64_t out[4]);
@@ -157,8 +157,11 @@ int vps_density_velocity_vector(vps_ctx* ctx, const float* vel_dev, const float*
  * and parallel_optimized.py:343-345).  Only x rows [x0,x0+nx) of the lattice are
  * produced.  out_dev: [C][nx][nqy][nqz] float32 = payload of the NN;
  * nn_idx_dev (may be NULL): [nx][nqy][nqz] int32.
- * work_dev: vps_nn_workspace_bytes(np, pos_is_f64) bytes of scratch.              */
-size_t vps_nn_workspace_bytes(int64_t np, int pos_is_f64);
+ * work_dev: vps_nn_workspace_bytes(np, pos_is_f64, nx*nqy*nqz) bytes of scratch (cell list, sorted
+ * records, and the list of lattice points the scatter pass leaves to the exact fallback search).
+ * Uniformly spaced axes (both reference lattices) take the particle-centric scatter search; any other
+ * axes the query-centric ring search -- same results.                                             */
+size_t vps_nn_workspace_bytes(int64_t np, int pos_is_f64, int64_t nq_slab);
 int vps_nn_resample(vps_ctx* ctx, const void* pos_dev, int pos_is_f64,
                     const float* payload_dev, int64_t np, int C,
                     const double* qx_host, int nqx, const double* qy_host, int nqy,

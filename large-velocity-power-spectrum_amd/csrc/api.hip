@@ -48,7 +48,7 @@ vps_launch_timer::~vps_launch_timer() {
 
 extern "C" {
 
-int vps_version(void) { return 1; }
+int vps_version(void) { return 2; }
 
 int vps_create(vps_ctx** out, int device_id) {
   if (!out) return vps_fail(nullptr, VPS_ERR_ARG, "vps_create: null out pointer");

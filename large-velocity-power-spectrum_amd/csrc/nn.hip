@@ -125,6 +125,8 @@ __global__ void __launch_bounds__(256)
 constexpr int NN_MAXCELL = 1024;   // staged bucket-offset entries (4 KiB)
 constexpr int NN_MAXREC = 1024;    // staged records (16 KiB)
 
+__device__ __forceinline__ float4 srec_load(const float4* __restrict__ srec, unsigned i) { return srec[i]; }
+
 struct NnBest {
   double best;
   float screen;
@@ -172,6 +174,44 @@ __device__ __forceinline__ bool nn_done(const NnGrid& g, const int (&c)[3], cons
   // slack: a particle may sit one rounding error outside its cell's nominal extent
   bound -= 1e-6 * fmax(g.w[0], fmax(g.w[1], g.w[2]));
   return bound > 0.0 && best < bound * bound;
+}
+
+
+// Exact search of one lattice point from global memory: Chebyshev rings r0, r0+1, ... of cells around the point's
+// own cell c, until the best squared distance is provably smaller than the distance to every unsearched cell.
+template <typename F>
+__device__ __forceinline__ void nn_ring_search(const F* __restrict__ pos, const float4* __restrict__ srec,
+                                               const unsigned* __restrict__ start, const NnGrid& g, const int (&c)[3],
+                                               const double (&Q)[3], const float (&Qf)[3], float err, int r0, NnBest& b) {
+  const int M = g.M;
+  bool finished = false;
+  for (int r = r0; r < M && !finished; ++r) {
+    const int xlo = max(c[0] - r, 0), xhi = min(c[0] + r, M - 1);
+    const int ylo = max(c[1] - r, 0), yhi = min(c[1] + r, M - 1);
+    for (int cx = xlo; cx <= xhi; ++cx) {
+      const bool xedge = (cx == c[0] - r) || (cx == c[0] + r);
+      for (int cy = ylo; cy <= yhi; ++cy) {
+        const bool edge = xedge || (cy == c[1] - r) || (cy == c[1] + r);
+        const long long rowbase = ((long long)cx * M + cy) * M;
+        // shell cells of this (cx,cy) column: the whole z run on an x/y face, else the two caps
+        const int nruns = (edge || r == 0) ? 1 : 2;
+        for (int run = 0; run < nruns; ++run) {
+          int z0, z1;
+          if (edge || r == 0) {
+            z0 = max(c[2] - r, 0);
+            z1 = min(c[2] + r, M - 1);
+          } else {
+            z0 = z1 = (run == 0) ? c[2] - r : c[2] + r;
+            if (z0 < 0 || z0 >= M) continue;
+          }
+          const unsigned s = start[rowbase + z0], e = start[rowbase + z1 + 1];
+          for (unsigned j = s; j < e; ++j) nn_consider<F>(pos, srec[j], Q, Qf, err, b);
+        }
+      }
+    }
+    bool exhausted;
+    finished = nn_done(g, c, Q, r, b.best, exhausted);
+  }
 }
 
 // Workgroup = 4 waves = a 4 x 4 x 16 tile of lattice points; wave w owns the 4 x 4 x 4
@@ -324,33 +364,7 @@ __global__ void __launch_bounds__(256)
     r0 = 2;
   }
   // general search from global memory: rings r0, r0+1, ... (rare after a staged scan)
-  for (int r = r0; r < M && !finished; ++r) {
-    const int xlo = max(c[0] - r, 0), xhi = min(c[0] + r, M - 1);
-    const int ylo = max(c[1] - r, 0), yhi = min(c[1] + r, M - 1);
-    for (int cx = xlo; cx <= xhi; ++cx) {
-      const bool xedge = (cx == c[0] - r) || (cx == c[0] + r);
-      for (int cy = ylo; cy <= yhi; ++cy) {
-        const bool edge = xedge || (cy == c[1] - r) || (cy == c[1] + r);
-        const long long rowbase = ((long long)cx * M + cy) * M;
-        // shell cells of this (cx,cy) column: the whole z run on an x/y face, else the two caps
-        const int nruns = (edge || r == 0) ? 1 : 2;
-        for (int run = 0; run < nruns; ++run) {
-          int z0, z1;
-          if (edge || r == 0) {
-            z0 = max(c[2] - r, 0);
-            z1 = min(c[2] + r, M - 1);
-          } else {
-            z0 = z1 = (run == 0) ? c[2] - r : c[2] + r;
-            if (z0 < 0 || z0 >= M) continue;
-          }
-          const unsigned s = start[rowbase + z0], e = start[rowbase + z1 + 1];
-          for (unsigned j = s; j < e; ++j) nn_consider<F>(pos, srec[j], Q, Qf, err, b);
-        }
-      }
-    }
-    bool exhausted;
-    finished = nn_done(g, c, Q, r, b.best, exhausted);
-  }
+  if (!finished) nn_ring_search<F>(pos, srec, start, g, c, Q, Qf, err, r0, b);
   // results leave through LDS so that 16 consecutive z (64 bytes per channel) are stored together
   lbest[(li * NN_BY + lj) * NN_BZ + wv * 4 + lk] = b.idx;
   __syncthreads();
@@ -370,6 +384,339 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Particle-centric search on a UNIFORM lattice (both reference lattices are: interp.py:1063 is a
+// linspace, scripts/parallel_optimized.py:343-346 is i * LCELL): the default path.
+//
+// The query-centric kernel above evaluates, for each of the ~21 lattice points per particle of C3,
+// every candidate of a wave-wide union of cells (~200 distance evaluations per point where one point
+// needs ~40).  Here the roles are swapped.  A workgroup owns a 16^3 tile of lattice points whose
+// running minima live in LDS as 64-bit keys (float32 squared distance bits << 32 | particle index);
+// every particle within a radius R of the tile visits only the lattice points inside its own R-box
+// (about (2R/h)^3 of them) and lowers their keys with one LDS atomic-min.  Per (point, particle) pair
+// the cost is one add, one LDS read of the current minimum and a compare; the atomic runs only when the
+// pair can still win.  R follows the local density (R = kappa * n_local^(-1/3), about 9 visits per lattice
+// point at kappa = 1.3), so dense and sparse tiles do comparable work per lattice point.
+//
+// Exactness (the oracle's rule: smallest float64 squared distance, lowest index on ties):
+//   * distances are evaluated in float32 on coordinates taken RELATIVE TO THE TILE CENTRE (subtracted in
+//     float64 first), so the error bound `err` of a float32 distance is ~2^-24 of the tile size, not of
+//     the box size;
+//   * a particle that could be the exact nearest one or tie with it has a float32 distance inside the
+//     screen (sqrt(b1) + 2 err)^2 of the smallest one b1 (as in the kernel above).  The atomic-min returns the
+//     previous key: of the final smallest and second-smallest keys, whichever arrives later sees the other,
+//     so comparing (old, mine) catches every point whose runner-up lies inside the winner's screen -- such a
+//     point is marked `contested`;
+//   * a point is `resolved` when its winner's distance is provably <= R: every particle within R has
+//     visited it (the R-box of a particle covers its R-ball).
+// Unresolved or contested points (voids, near-ties, duplicates: ~1e-4 of the points on the BASELINE configs) are
+// appended to a list and finished by nn_fallback_kernel with the exact float64 ring search.
+// ------------------------------------------------------------------------------------------------
+constexpr int NT_T = 16;                  // lattice tile edge
+constexpr int NT_PTS = NT_T * NT_T * NT_T;
+constexpr int NT_MAXCOL = 1024;           // cell columns of a tile's search region staged in LDS
+constexpr int NT_THREADS = 256;
+
+struct NnScatterParams {
+  const float4* srec;
+  const unsigned* start;
+  NnGrid g;
+  const double* qx;   // device lattice axes (the slab's x rows start at qx[x0])
+  const double* qy;
+  const double* qz;
+  int x0, nx, nqy, nqz;
+  double a0[3], h[3];   // uniform model of the axes, q_a[i] ~ a0[a] + i h[a] (|deviation| <= 0.2 h, host-checked)
+  float slack[3];       // measured max |q_a[i] - (a0 + i h)| / |h|, plus 2e-3 for the float32 index arithmetic
+  float kappa;
+  int ablate;           // timing experiments only: skip the atomics (results are garbage)
+  const float* payload;
+  float* out;
+  int* nn_idx;
+  unsigned* list;        // unresolved lattice points (offsets inside the slab), capacity = all points
+  unsigned* list_count;
+};
+
+// exclusive scan of a[0..1023] in LDS by 256 threads (4 entries each); returns the total
+__device__ __forceinline__ unsigned block_scan_1024(unsigned* a, unsigned* wsum, int tid) {
+  unsigned v0 = a[4 * tid], v1 = a[4 * tid + 1], v2 = a[4 * tid + 2], v3 = a[4 * tid + 3];
+  const unsigned mine = v0 + v1 + v2 + v3;
+  unsigned incl = mine;
+  const int lane = tid & 63;
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  unsigned base = 0;
+  for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+  const unsigned total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  unsigned run = base + incl - mine;
+  a[4 * tid] = run; run += v0;
+  a[4 * tid + 1] = run; run += v1;
+  a[4 * tid + 2] = run; run += v2;
+  a[4 * tid + 3] = run;
+  __syncthreads();
+  return total;
+}
+
+template <typename F, int C>
+__global__ void __launch_bounds__(NT_THREADS) nn_scatter_kernel(const F* __restrict__ pos, const NnScatterParams p) {
+  __shared__ unsigned long long key[NT_PTS + 8];
+  __shared__ unsigned char contested[NT_PTS];
+  __shared__ unsigned colbase[NT_MAXCOL + 4];   // exclusive prefix of the column run lengths
+  __shared__ unsigned colg0[NT_MAXCOL];         // first record of each column's z run
+  __shared__ float qf[3][NT_T];                 // lattice coordinates relative to the tile centre
+  __shared__ unsigned wsum[4];
+  __shared__ unsigned s_count;
+
+  const int tid = threadIdx.x;
+  const int ntz = (p.nqz + NT_T - 1) / NT_T, nty = (p.nqy + NT_T - 1) / NT_T;
+  const long long tile = blockIdx.x;
+  const int t0[3] = {(int)(tile / ((long long)ntz * nty)) * NT_T, (int)((tile / ntz) % nty) * NT_T, (int)(tile % ntz) * NT_T};
+  const int nq[3] = {p.nx, p.nqy, p.nqz};
+  const double* ax[3] = {p.qx + p.x0, p.qy, p.qz};
+  int nt[3];
+  double lo[3], hi[3], org[3];
+  const NnGrid& g = p.g;
+  const int M = g.M;
+  const unsigned* __restrict__ start = p.start;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    nt[a] = min(NT_T, nq[a] - t0[a]);
+    const double qa = ax[a][t0[a]], qb = ax[a][t0[a] + nt[a] - 1];
+    lo[a] = fmin(qa, qb);
+    hi[a] = fmax(qa, qb);
+    org[a] = 0.5 * (qa + qb);
+  }
+  if (tid < 3 * NT_T) {
+    const int a = tid / NT_T, i = tid % NT_T;
+    qf[a][i] = (float)(ax[a][t0[a] + min(i, nt[a] - 1)] - org[a]);
+  }
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+
+  // ---- local density -> search radius ----
+  int c0[3], c1[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    c0[a] = cell_coord(lo[a], g.lo[a], g.inv_w[a], M);
+    c1[a] = cell_coord(hi[a], g.lo[a], g.inv_w[a], M);
+  }
+  {
+    const int ny0 = c1[1] - c0[1] + 1, ncol0 = (c1[0] - c0[0] + 1) * ny0;
+    unsigned cnt = 0;
+    for (int col = tid; col < ncol0; col += NT_THREADS) {
+      const long long row = ((long long)(c0[0] + col / ny0) * M + (c0[1] + col % ny0)) * M;
+      cnt += start[row + c1[2] + 1] - start[row + c0[2]];
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((tid & 63) == 0 && cnt) atomicAdd(&s_count, cnt);
+  }
+  __syncthreads();
+  const double hmax = fmax(fabs(p.h[0]), fmax(fabs(p.h[1]), fabs(p.h[2])));
+  const double rmax = (double)NT_T * hmax;
+  double R;
+  {
+    const double vol = ((c1[0] - c0[0] + 1) * g.w[0]) * ((c1[1] - c0[1] + 1) * g.w[1]) * ((c1[2] - c0[2] + 1) * g.w[2]);
+    const unsigned cnt = s_count;
+    R = cnt ? (double)p.kappa * cbrt(vol / (double)cnt) : rmax;
+    R = fmin(R, rmax);
+  }
+  // region of cells whose particles can lie within R of the tile; shrink R until its columns fit the staging
+  int r0[3], r1[3], ncy, ncol;
+  for (;;) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      r0[a] = cell_coord(lo[a] - R, g.lo[a], g.inv_w[a], M);
+      r1[a] = cell_coord(hi[a] + R, g.lo[a], g.inv_w[a], M);
+    }
+    ncy = r1[1] - r0[1] + 1;
+    ncol = (r1[0] - r0[0] + 1) * ncy;
+    if (ncol <= NT_MAXCOL) break;
+    R *= 0.7;
+  }
+  const float Rf = (float)R;
+  // float32 error bound of a distance between tile-relative coordinates (see nn_run for the constant)
+  double half = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) half = fmax(half, 0.5 * (hi[a] - lo[a]));
+  const float err = (float)((2.0 * half + R + hmax) * 2.5e-7);
+  // keys start at R^2: a pair farther than that never enters
+  const float c_init = Rf * Rf;
+  // cheap upper bound of the screen (sqrt(c)(1+1e-6) + 2 err)^2 (1+1e-6) of a current minimum c <= R^2
+  const float alpha = 1.0f + 4e-6f;
+  const float beta = 4.01f * err * (Rf * 1.01f) + 4.01f * err * err;
+  {
+    const unsigned long long k0 = ((unsigned long long)__float_as_uint(c_init) << 32) | 0xffffffffull;
+    for (int i = tid; i < NT_PTS; i += NT_THREADS) {
+      key[i] = k0;
+      contested[i] = 0;
+    }
+    for (int col = tid; col < NT_MAXCOL; col += NT_THREADS) {
+      unsigned n = 0;
+      if (col < ncol) {
+        const long long row = ((long long)(r0[0] + col / ncy) * M + (r0[1] + col % ncy)) * M;
+        const unsigned g0 = start[row + r0[2]];
+        colg0[col] = g0;
+        n = start[row + r1[2] + 1] - g0;
+      }
+      colbase[col] = n;
+    }
+  }
+  __syncthreads();
+  const unsigned total = block_scan_1024(colbase, wsum, tid);
+  if (tid == 0) colbase[NT_MAXCOL] = total;
+  __syncthreads();
+
+  // ---- scatter: one particle per thread ----
+  float inv_h[3], a0f[3];   // index of a tile-relative coordinate v on axis a: (v - a0f) * inv_h
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    inv_h[a] = (float)(1.0 / p.h[a]);
+    a0f[a] = (float)(p.a0[a] + (double)((a == 0 ? p.x0 : 0) + t0[a]) * p.h[a] - org[a]);
+  }
+  unsigned* key32 = reinterpret_cast<unsigned*>(key);
+  for (unsigned j = tid; j < total; j += NT_THREADS) {
+    // column of item j: largest col with colbase[col] <= j
+    int a_ = 0, b_ = ncol;
+    while (b_ - a_ > 1) {
+      const int m = (a_ + b_) >> 1;
+      if (colbase[m] <= j) a_ = m; else b_ = m;
+    }
+    const float4 rec = srec_load(p.srec, colg0[a_] + (j - colbase[a_]));
+    const int oi = __float_as_int(rec.w);
+    double pd[3];
+    if constexpr (sizeof(F) == 4) {
+      pd[0] = (double)rec.x; pd[1] = (double)rec.y; pd[2] = (double)rec.z;
+    } else {
+      pd[0] = pos[(long long)oi * 3 + 0]; pd[1] = pos[(long long)oi * 3 + 1]; pd[2] = pos[(long long)oi * 3 + 2];
+    }
+    const float pr[3] = {(float)(pd[0] - org[0]), (float)(pd[1] - org[1]), (float)(pd[2] - org[2])};
+    // lattice indices (tile-local) whose coordinate can be within R of the particle: every integer of
+    // [(p - R - a0)/h - slack, (p + R - a0)/h + slack], slack = measured deviation of the axis from uniform
+    // (in units of h) + float32 rounding of this arithmetic
+    int i0[3], i1[3];
+    bool any = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float u0 = (pr[a] - Rf - a0f[a]) * inv_h[a], u1 = (pr[a] + Rf - a0f[a]) * inv_h[a];
+      const float ulo = fminf(u0, u1), uhi = fmaxf(u0, u1);
+      i0[a] = max(0, (int)ceilf(ulo - p.slack[a]));
+      i1[a] = min(nt[a] - 1, (int)floorf(uhi + p.slack[a]));
+      any = any && (i0[a] <= i1[a]);
+    }
+    if (!any) continue;
+    const unsigned long long mine_lo = (unsigned long long)(unsigned)oi;
+    // z in chunks of 8 (one chunk when 2R < 8 h, the usual case): the chunk's fz^2 stay in registers, the 8 current
+    // minima of a (ix, iy) row are read together, so the LDS latency is paid once per row, not once per pair
+    for (int zb = i0[2]; zb <= i1[2]; zb += 8) {
+      float fz2[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float fz = qf[2][min(zb + k, NT_T - 1)] - pr[2];
+        fz2[k] = (zb + k <= i1[2]) ? fz * fz : INFINITY;     // beyond the box: never a candidate
+      }
+      for (int ix = i0[0]; ix <= i1[0]; ++ix) {
+        const float fx = qf[0][ix] - pr[0];
+        const float fx2 = fx * fx;
+        for (int iy = i0[1]; iy <= i1[1]; ++iy) {
+          const float fy = qf[1][iy] - pr[1];
+          const float t2 = fx2 + fy * fy;
+          const int q0 = (ix * NT_T + iy) * NT_T + zb;
+          // The 8 current minima of the row are read together (one LDS latency per row) and screened into a bit mask: a
+          // pair goes on only if it can still win or tie.  The survivors (few per lane and row) are then worked off lowest
+          // bit first, so a wave issues as many atomic instructions per row as its busiest lane has survivors, not eight.
+          // The atomic-min returns the previous key: of the final smallest and second-smallest keys whichever arrives
+          // later sees the other one, so comparing (old, mine) catches every point whose runner-up lies inside the
+          // winner's screen -- `contested`.
+          unsigned m = 0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float cur = __uint_as_float(key32[2 * (q0 + k) + 1]);   // (the array is padded by 8 keys)
+            const float d2 = t2 + fz2[k];
+            m |= (d2 <= cur * alpha + beta && d2 <= c_init) ? (1u << k) : 0u;
+          }
+          if (p.ablate) m = 0;
+          while (m) {
+            const int k = __builtin_ctz(m);
+            m &= m - 1;
+            const float fz = qf[2][min(zb + k, NT_T - 1)] - pr[2];
+            const float d2 = t2 + fz * fz;
+            const int q = q0 + k;
+            const unsigned long long mine = ((unsigned long long)__float_as_uint(d2) << 32) | mine_lo;
+            const unsigned long long old = atomicMin(&key[q], mine);
+            const unsigned long long klo = old < mine ? old : mine, khi = old < mine ? mine : old;
+            const float dlo = __uint_as_float((unsigned)(klo >> 32)), dhi = __uint_as_float((unsigned)(khi >> 32));
+            // (a key that still carries the start value 0xffffffff is nobody's candidate)
+            if ((unsigned)khi != 0xffffffffu && (unsigned)klo != 0xffffffffu && (unsigned)klo != (unsigned)khi &&
+                dhi <= dlo * alpha + beta) {
+              const float rb = sqrtf(dlo) * 1.000001f + 2.f * err;
+              if (dhi <= rb * rb * 1.000001f) contested[q] = 1;
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: 16 consecutive z per row leave together ----
+  const long long nqs = (long long)p.nx * p.nqy * p.nqz;
+  for (int i = tid; i < NT_PTS; i += NT_THREADS) {
+    const int iz = i % NT_T, iy = (i / NT_T) % NT_T, ix = i / (NT_T * NT_T);
+    if (ix >= nt[0] || iy >= nt[1] || iz >= nt[2]) continue;
+    const unsigned long long k = key[i];
+    const unsigned bi = p.ablate ? 0u : (unsigned)k;     // (timing experiments: any valid index)
+    const float d = __uint_as_float((unsigned)(k >> 32));
+    const long long q = ((long long)(t0[0] + ix) * p.nqy + (t0[1] + iy)) * p.nqz + (t0[2] + iz);
+    // settled: the winner's whole screen lies inside the sphere of radius R (every particle that could beat or tie it
+    // has therefore visited), and no runner-up was seen inside that screen (so the float32 winner is the exact one;
+    // ties and near-ties land in the fallback)
+    const float rb = sqrtf(d) * 1.000001f + 2.f * err;
+    const float screen = rb * rb * 1.000001f;
+    const bool ok = (bi != 0xffffffffu && screen <= c_init && !contested[i]) || p.ablate;
+    if (ok) {
+      if (p.nn_idx) p.nn_idx[q] = (int)bi;
+      if (p.out) {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) p.out[(long long)ch * nqs + q] = p.payload[(long long)bi * C + ch];
+      }
+    } else {
+      p.list[atomicAdd(p.list_count, 1u)] = (unsigned)q;
+    }
+  }
+}
+
+// the lattice points the scatter pass could not settle: exact float64 ring search, one point per thread
+template <typename F, int C>
+__global__ void __launch_bounds__(256)
+    nn_fallback_kernel(const F* __restrict__ pos, const float4* __restrict__ srec, const unsigned* __restrict__ start,
+                       NnGrid g, float err, const double* __restrict__ qx, const double* __restrict__ qy,
+                       const double* __restrict__ qz, int x0, int nx, int nqy, int nqz,
+                       const unsigned* __restrict__ list, const unsigned* __restrict__ list_count,
+                       const float* __restrict__ payload, float* __restrict__ out, int* __restrict__ nn_idx) {
+  const unsigned n = *list_count;
+  const long long nqs = (long long)nx * nqy * nqz;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned q = list[i];
+    const int iz = (int)(q % (unsigned)nqz), iy = (int)((q / (unsigned)nqz) % (unsigned)nqy), ix = (int)(q / ((unsigned)nqz * (unsigned)nqy));
+    const double Q[3] = {qx[x0 + ix], qy[iy], qz[iz]};
+    const float Qf[3] = {(float)Q[0], (float)Q[1], (float)Q[2]};
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = cell_coord(Q[a], g.lo[a], g.inv_w[a], g.M);
+    NnBest b{INFINITY, INFINITY, 0x7fffffff};
+    nn_ring_search<F>(pos, srec, start, g, c, Q, Qf, err, 0, b);
+    if (nn_idx) nn_idx[q] = b.idx;
+    if (out) {
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) out[(long long)ch * nqs + q] = payload[(long long)b.idx * C + ch];
+    }
+  }
+}
+
 int nn_grid_side(int64_t np) {
   // cells per axis from the particles per cell: 1.5 measured best (sweep 0.7 .. 3) -- the staged
   // union of cells per 4x4x4 query block grows with smaller cells, the ring-2 fallbacks with larger
@@ -382,12 +729,12 @@ int nn_grid_side(int64_t np) {
 }
 
 struct NnLayout {
-  size_t header, count, fill, start, tiles, srec, total;
+  size_t header, count, fill, start, tiles, srec, list, list_count, total;
   long long ncell, ntiles;
   int M;
 };
 
-NnLayout nn_layout(int64_t np, int /*is_f64*/) {
+NnLayout nn_layout(int64_t np, int /*is_f64*/, int64_t nq_slab) {
   NnLayout l;
   l.M = nn_grid_side(np);
   l.ncell = (long long)l.M * l.M * l.M;
@@ -400,15 +747,37 @@ NnLayout nn_layout(int64_t np, int /*is_f64*/) {
   l.start = off;  off = align(off + sizeof(unsigned) * (l.ncell + 1));
   l.tiles = off;  off = align(off + sizeof(unsigned) * (l.ntiles + 1));
   l.srec = off;   off = align(off + (size_t)np * sizeof(float4));
+  l.list_count = off; off = align(off + sizeof(unsigned));
+  l.list = off;   off = align(off + (size_t)(nq_slab > 0 ? nq_slab : 0) * sizeof(unsigned));   // unresolved points of the scatter pass
   l.total = off;
   return l;
 }
 
+// q[i] ~ a0 + i h with |deviation| <= 0.2 |h| (what the scatter kernel's index ranges allow for)
+bool nn_axis_uniform(const double* q, int n, double* a0, double* h, double* dev) {
+  *a0 = q[0];
+  *h = n > 1 ? (q[n - 1] - q[0]) / (double)(n - 1) : 1.0;
+  *dev = 0.0;
+  if (!(*h != 0.0) || !std::isfinite(*h)) return false;
+  for (int i = 0; i < n; ++i) {
+    const double d = std::fabs(q[i] - (*a0 + (double)i * *h)) / std::fabs(*h);
+    if (!(d <= 0.2)) return false;
+    *dev = std::fmax(*dev, d);
+  }
+  return true;
+}
+
+struct NnAxesModel {
+  bool uniform;
+  double a0[3], h[3], dev[3];
+};
+
 template <typename F>
 int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, int x0, int nx,
            int nqy, int nqz, const double* dqx, const double* dqy, const double* dqz, double qmax,
-           float* out, int* nn_idx, char* work) {
-  const NnLayout l = nn_layout(np, sizeof(F) == 8);
+           const NnAxesModel& model, float* out, int* nn_idx, char* work) {
+  const long long nq_slab = (long long)nx * nqy * nqz;
+  const NnLayout l = nn_layout(np, sizeof(F) == 8, nq_slab);
   NnHeader* hdr = reinterpret_cast<NnHeader*>(work + l.header);
   unsigned* count = reinterpret_cast<unsigned*>(work + l.count);
   unsigned* fill = reinterpret_cast<unsigned*>(work + l.fill);
@@ -453,6 +822,54 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
     hipLaunchKernelGGL(nn_fill_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np, g, start, fill, srec);
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
+  // uniform lattice (both reference lattices): particle-centric scatter + exact fallback for the few open points
+  if (model.uniform && nq_slab < 0xffffffffLL && !getenv("VPS_NN_QUERY_CENTRIC")) {
+    NnScatterParams sp{};
+    sp.srec = srec;
+    sp.start = start;
+    sp.g = g;
+    sp.qx = dqx; sp.qy = dqy; sp.qz = dqz;
+    sp.x0 = x0; sp.nx = nx; sp.nqy = nqy; sp.nqz = nqz;
+    for (int a = 0; a < 3; ++a) { sp.a0[a] = model.a0[a]; sp.h[a] = model.h[a]; sp.slack[a] = (float)(model.dev[a] + 2e-3); }
+    const char* kenv = getenv("VPS_NN_KAPPA");
+    sp.kappa = kenv ? (float)atof(kenv) : 1.15f;
+    if (!(sp.kappa > 0.2f && sp.kappa < 8.f)) sp.kappa = 1.15f;
+    sp.ablate = getenv("VPS_NN_ABLATE") ? 1 : 0;
+    sp.payload = payload;
+    sp.out = out;
+    sp.nn_idx = nn_idx;
+    sp.list = reinterpret_cast<unsigned*>(work + l.list);
+    sp.list_count = reinterpret_cast<unsigned*>(work + l.list_count);
+    const long long tiles = (long long)((nx + NT_T - 1) / NT_T) * ((nqy + NT_T - 1) / NT_T) * ((nqz + NT_T - 1) / NT_T);
+    if (tiles > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_nn_resample: too many queries for one launch");
+    VPS_HIP_CHECK(ctx, hipMemsetAsync(sp.list_count, 0, sizeof(unsigned), ctx->stream));
+    {
+      vps_launch_timer tm(ctx, VPS_K_NN_QUERY);
+#define VPS_NNS(CC)                                                                                            \
+  do {                                                                                                         \
+    hipLaunchKernelGGL((nn_scatter_kernel<F, CC>), dim3((unsigned)tiles), dim3(NT_THREADS), 0, ctx->stream, pos, sp); \
+    hipLaunchKernelGGL((nn_fallback_kernel<F, CC>), dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, ctx->stream, \
+                       pos, srec, start, g, err, dqx, dqy, dqz, x0, nx, nqy, nqz, sp.list, sp.list_count, payload, \
+                       out, nn_idx);                                                                           \
+  } while (0)
+      switch (C) {
+        case 1: VPS_NNS(1); break;
+        case 3: VPS_NNS(3); break;
+        case 4: VPS_NNS(4); break;
+        default: return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "nn_resample: C=%d channels (supported: 1,3,4)", C);
+      }
+#undef VPS_NNS
+    }
+    VPS_HIP_CHECK(ctx, hipGetLastError());
+    if (ctx->timing || getenv("VPS_NN_STATS")) {   // diagnostics: how many points the scatter pass left open
+      unsigned open_pts = 0;
+      VPS_HIP_CHECK(ctx, hipMemcpyAsync(&open_pts, sp.list_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+      VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->nn_open_points = open_pts;
+      if (getenv("VPS_NN_STATS")) fprintf(stderr, "[vps] nn: %u of %lld lattice points left to the exact fallback\n", open_pts, nq_slab);
+    }
+    return VPS_OK;
+  }
   const long long qblocks = (long long)((nx + NN_BX - 1) / NN_BX) * ((nqy + NN_BY - 1) / NN_BY) * ((nqz + NN_BZ - 1) / NN_BZ);
   if (qblocks > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_nn_resample: too many queries for one launch");
   {
@@ -476,9 +893,9 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
 
 extern "C" {
 
-size_t vps_nn_workspace_bytes(int64_t np, int pos_is_f64) {
+size_t vps_nn_workspace_bytes(int64_t np, int pos_is_f64, int64_t nq_slab) {
   if (np < 1) return 256;
-  return nn_layout(np, pos_is_f64).total;
+  return nn_layout(np, pos_is_f64, nq_slab).total;
 }
 
 int vps_nn_resample(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* payload_dev,
@@ -515,11 +932,23 @@ int vps_nn_resample(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const flo
   for (int i = 0; i < nqy; ++i) qmax = std::fmax(qmax, std::fabs(qy_host[i]));
   for (int i = 0; i < nqz; ++i) qmax = std::fmax(qmax, std::fabs(qz_host[i]));
   if (!std::isfinite(qmax)) return vps_fail(ctx, VPS_ERR_ARG, "vps_nn_resample: lattice axes are not finite");
+  NnAxesModel model;
+  model.uniform = nn_axis_uniform(qx_host, nqx, &model.a0[0], &model.h[0], &model.dev[0]) &&
+                  nn_axis_uniform(qy_host, nqy, &model.a0[1], &model.h[1], &model.dev[1]) &&
+                  nn_axis_uniform(qz_host, nqz, &model.a0[2], &model.h[2], &model.dev[2]);
+  {   // an axis with a single point has no spacing of its own: give it its neighbours' (it only scales the search radius cap)
+    const int nn[3] = {nqx, nqy, nqz};
+    double hm = 0.0;
+    for (int a = 0; a < 3; ++a)
+      if (nn[a] > 1) hm = std::fmax(hm, std::fabs(model.h[a]));
+    for (int a = 0; a < 3; ++a)
+      if (nn[a] == 1) model.h[a] = hm > 0.0 ? hm : 1.0;
+  }
   if (pos_is_f64)
     return nn_run<double>(ctx, reinterpret_cast<const double*>(pos_dev), payload_dev, np, C, x0, nx, nqy,
-                          nqz, dqx, dqy, dqz, qmax, out_dev, nn_idx_dev, work);
+                          nqz, dqx, dqy, dqz, qmax, model, out_dev, nn_idx_dev, work);
   return nn_run<float>(ctx, reinterpret_cast<const float*>(pos_dev), payload_dev, np, C, x0, nx, nqy, nqz,
-                       dqx, dqy, dqz, qmax, out_dev, nn_idx_dev, work);
+                       dqx, dqy, dqz, qmax, model, out_dev, nn_idx_dev, work);
 }
 
 }  // extern "C"

@@ -46,6 +46,8 @@ struct vps_ctx {
   double* d_axes = nullptr;
   size_t axes_cap = 0;
 
+  unsigned nn_open_points = 0;   // diagnostics: lattice points the last NN scatter pass left to the exact fallback
+
   bool timing = false;
   std::vector<vps_timed_launch> launches;
   std::vector<hipEvent_t> event_pool;

@@ -52,7 +52,7 @@ SYMBOLS = (
     ("vps_deposit_fft_zy", C.c_int, (_vp, _vp, C.c_int, _vp, _vp, _i64, C.c_int, C.c_double, C.c_int, C.c_int,
                                      C.c_int, C.c_int, _vp, _vp, _vp)),
     ("vps_density_velocity_vector", C.c_int, (_vp, _vp, _vp, _i64, _vp)),
-    ("vps_nn_workspace_bytes", C.c_size_t, (_i64, C.c_int)),
+    ("vps_nn_workspace_bytes", C.c_size_t, (_i64, C.c_int, _i64)),
     ("vps_nn_resample", C.c_int, (_vp, _vp, C.c_int, _vp, _i64, C.c_int, _dp, C.c_int, _dp, C.c_int,
                                   _dp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp)),
     ("vps_field_algebra", C.c_int, (_vp, C.c_int, C.c_int, C.c_double, _vp, _i64)),

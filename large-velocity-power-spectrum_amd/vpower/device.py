@@ -317,7 +317,7 @@ class HipKernels:
             out = self.empty((C_, nx, len(ax[1]), len(ax[2])), torch.float32)
         idx = self.empty((nx, len(ax[1]), len(ax[2])), torch.int32) if want_index else None
         kind = self._pos_kind(pos)
-        work = self.workspace("nn", self.lib.vps_nn_workspace_bytes(pos.shape[0], kind))
+        work = self.workspace("nn", self.lib.vps_nn_workspace_bytes(pos.shape[0], kind, nx * len(ax[1]) * len(ax[2])))
         self._chk(self.lib.vps_nn_resample(self.ctx, self._ptr(pos), kind, self._ptr(payload, torch.float32),
                                            pos.shape[0], C_, _ffi.as_dp(ax[0]), len(ax[0]),
                                            _ffi.as_dp(ax[1]), len(ax[1]), _ffi.as_dp(ax[2]), len(ax[2]),

@@ -435,3 +435,38 @@ def test_context_device_need_not_be_current():
     ref = np.fft.fftn(f.cpu().numpy().astype(np.float64))[:, :, :17].transpose(2, 1, 0)               # [kz <= N/2, ky, kx]
     assert out.device.index == 1 and np.allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
     K1.close()
+
+
+# ------------------------------------------------- the two exact-NN search kernels ----
+def test_nn_scatter_and_query_centric_kernels_agree(K, monkeypatch):
+    """Uniform lattices take the particle-centric scatter kernel, anything else the query-centric ring search;
+    both are exact, so they agree with each other and with the oracle -- including clumps, voids larger than
+    the scatter radius (finished by the fallback search), duplicated particles and a descending axis."""
+    rng = np.random.default_rng(77)
+    Np, N, L = 40000, 48, 1.0
+    pos = rng.random((Np, 3)).astype(np.float32)
+    pos[:8000] = (0.2 + 0.004 * rng.standard_normal((8000, 3))).astype(np.float32)   # clump
+    pos[8000:30000, 0] *= 0.4                                                         # a void at x > 0.4 for most of them
+    pos[100:110] = pos[100]                                                           # duplicates: lowest index wins
+    ax = orc.lattice_axes_library(L, N)
+    payload = K.zeros((Np, 1), torch.float32)
+    dpos = K.to_device(pos)
+    ref = orc.exact_nn_lattice(pos, ax, ax, ax)
+    _, i1 = K.nn_resample(dpos, payload, (ax, ax, ax), 0, N, want_index=True)
+    monkeypatch.setenv("VPS_NN_QUERY_CENTRIC", "1")
+    _, i2 = K.nn_resample(dpos, payload, (ax, ax, ax), 0, N, want_index=True)
+    monkeypatch.delenv("VPS_NN_QUERY_CENTRIC")
+    assert np.array_equal(i1.cpu().numpy().ravel(), ref) and np.array_equal(i2.cpu().numpy().ravel(), ref)
+    # descending z axis, x-slab [8, 24): still the scatter kernel
+    axr = ax[::-1].copy()
+    _, i3 = K.nn_resample(dpos, payload, (ax, ax, axr), 8, 16, want_index=True)
+    assert np.array_equal(i3.cpu().numpy().ravel(), orc.exact_nn_lattice(pos, ax[8:24], ax, axr))
+    # non-uniform axes: the ring search
+    ay = np.sort(rng.random(20)) * L
+    az = np.cumsum(np.exp(rng.standard_normal(24))) / 30
+    _, i4 = K.nn_resample(dpos, payload, (ax[:12], ay, az), 0, 12, want_index=True)
+    assert np.array_equal(i4.cpu().numpy().ravel(), orc.exact_nn_lattice(pos, ax[:12], ay, az))
+    # float64 positions through the scatter kernel
+    pos64 = pos.astype(np.float64) * (1 + 1e-9)
+    _, i5 = K.nn_resample(K.to_device(pos64), payload, (ax, ax, ax), 0, N, want_index=True)
+    assert np.array_equal(i5.cpu().numpy().ravel(), orc.exact_nn_lattice(pos64, ax, ax, ax))

@@ -24,10 +24,10 @@ def test_abi_exports_every_declared_symbol():
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vps_version() == 1
+    assert lib.vps_version() == 2
     assert lib.vps_fft_supported(512) == 1 and lib.vps_fft_supported(500) == 1 and lib.vps_fft_supported(768) == 1 and lib.vps_fft_supported(2000) == 1 and lib.vps_fft_supported(600) == 0
     assert lib.vps_fft_workspace_bytes(512, 512) == (512 * 256 * 512 + 512 * 512) * 8
-    assert lib.vps_nn_workspace_bytes(10 ** 6, 0) > 10 ** 6 * 16
+    assert lib.vps_nn_workspace_bytes(10 ** 6, 0, 64 ** 3) > 10 ** 6 * 16 + 4 * 64 ** 3
 
 
 def test_product_path_fails_loudly_without_gpu():
