@@ -970,7 +970,7 @@ int vps_deposit_fft_zy_supported(vps_ctx* ctx, int N, int quantity) {
 
 size_t vps_deposit_fft_zy_workspace_bytes(int64_t np, int N, int nx) {
   if (np < 0 || N < 16 || nx < 1) return 0;
-  const Bricks b = make_pencils(N, 0, nx, vps_pencil_tp());
+  const Bricks b = make_pencils(N, 0, nx, vps_pencil_tp(N));
   const size_t sort = dep_layout(np, 4, b).total;
   const size_t images = 3 * ((size_t)nx * (N / 2) * N + (size_t)nx * N) * sizeof(float2);
   return sort + images;
@@ -986,7 +986,7 @@ int vps_deposit_fft_zy(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const 
     return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_deposit_fft_zy: N=%d quantity=%d not supported by the fused path", N, quantity);
   if (!spec_dev || !nyq_dev || !work_dev || (np > 0 && (!pos_dev || !vel_dev || !rho_dev)))
     return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_fft_zy: null buffer");
-  const Bricks b = make_pencils(N, x0, nx, vps_pencil_tp());
+  const Bricks b = make_pencils(N, x0, nx, vps_pencil_tp(N));
   char* work = reinterpret_cast<char*>(work_dev);
   DepLayout l;
   if (flags & VPS_FLAG_REUSE_SORT) {

@@ -664,8 +664,20 @@ struct PencilParams {
 #define VPS_PENCIL_MINW 4
 #endif
 
+// 2048-cell lines (NC = 1024): 16 transform registers + 16 scale factors per lane (+ 16 energy sums) do not fit the 128
+// VGPRs that four waves per SIMD allow -- the kernel spilled 88 (292: energy) bytes per lane to scratch, and the scratch
+// traffic (PMC: 141 GB written per velocity launch against 103 GB of output, 158 GB against 34 GB for energy) was what
+// the launch waited for.  Two waves per SIMD (one 8-line workgroup per CU) keep everything in registers.
+#ifndef VPS_PENCIL_MINW_LONG
+#define VPS_PENCIL_MINW_LONG 2
+#endif
+template <int NC>
+constexpr int pencil_min_waves() {
+  return NC >= 1024 ? VPS_PENCIL_MINW_LONG : VPS_PENCIL_MINW;
+}
+
 template <int NC, int TP, bool ENERGY = false>
-__global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_fft_z_kernel(const PencilParams p) {
+__global__ void __launch_bounds__(TP* PlanInfo<NC>::L, pencil_min_waves<NC>()) pencil_fft_z_kernel(const PencilParams p) {
   typedef PlanInfo<NC> PI;
   constexpr int L = PI::L, RL = PI::RL, NT = TP * L, N = 2 * NC;
   constexpr int ACC = TP * N;                       // floats of one accumulator
@@ -682,7 +694,18 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
 
   const int tid = threadIdx.x;
   const int t = tid / L, l = tid % L;
-  const unsigned pencil = blockIdx.x;
+  // Pencils narrower than a 128-byte output line (TP < 16): the 16/TP pencils that share output lines are consecutive
+  // pencil numbers; run them on ONE XCD, close in time, so that its L2 merges their partial-line writes (same map as
+  // fft_transpose_pass: hardware block h = 8 s + x handles logical pencil G*(8*(s/G) + x) + s%G)
+  unsigned pencil = blockIdx.x;
+  constexpr unsigned GP = (TP < 16) ? 16 / TP : 1;
+  if constexpr (GP > 1) {
+    const unsigned span = 8 * GP;
+    if (pencil / span < gridDim.x / span) {   // whole groups only; the tail keeps the identity map
+      const unsigned base = (pencil / span) * span, h = pencil % span;
+      pencil = base + GP * (h % 8) + (h / 8);
+    }
+  }
   const int x = pencil / p.nby, y0 = (pencil % p.nby) * TP;
   const unsigned s = p.start[pencil], e = p.start[pencil + 1];
   // more than two particles per cell on average: hot cells are likely, take the native atomics (vps_lds_add)
@@ -801,11 +824,23 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, VPS_PENCIL_MINW) pencil_f
   }
 }
 
-constexpr int PENCIL_TP = 16;
+// y-lines per pencil: 16 (128-byte output segments); 8 for 2048-cell lines: 16 lines are 1024 threads = four waves per
+// SIMD, i.e. 128 VGPRs, which the kernel does not fit into (see pencil_min_waves); 8 lines leave the register budget open.
+// The two pencils that complete a 128-byte output line are placed on one XCD (remap in the kernel).  Measured at C4
+// (2048^3, per step of 7 fields): 16 lines with spills 111 ms, 8 lines with spills 118 ms, 8 lines without 106 ms,
+// 4 lines (32-byte segments, 3 workgroups per CU) 228 ms.
+#ifndef VPS_PENCIL_TP_LONG
+#define VPS_PENCIL_TP_LONG 8
+#endif
+template <int NC>
+constexpr int pencil_tp() {
+  return NC >= 1024 ? VPS_PENCIL_TP_LONG : 16;
+}
 
 template <int NC>
 size_t pencil_lds_bytes() {
   typedef PlanInfo<NC> PI;
+  constexpr int PENCIL_TP = pencil_tp<NC>();
   constexpr int ACC = PENCIL_TP * 2 * NC, LINES = PENCIL_TP * PI::PITCH * 2;
   return (size_t)(ACC > LINES ? ACC : LINES) * sizeof(float) + (size_t)PI::TWL * sizeof(cf);
 }
@@ -814,6 +849,7 @@ template <int NC>
 int launch_pencil(vps_ctx* ctx, const PencilParams& p, long long npencils) {
   typedef PlanInfo<NC> PI;
   const size_t lds = pencil_lds_bytes<NC>();
+  constexpr int PENCIL_TP = pencil_tp<NC>();
   if (lds > ctx->lds_per_cu) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "pencil kernel needs %zu B LDS", lds);
   auto kern = p.energy ? pencil_fft_z_kernel<NC, PENCIL_TP, true> : pencil_fft_z_kernel<NC, PENCIL_TP, false>;
   if (lds > 64 * 1024)
@@ -832,6 +868,9 @@ int launch_pencil(vps_ctx* ctx, const PencilParams& p, long long npencils) {
 // binned straight from registers (MODE 0) or written in place order (MODE 1).
 // Persistent workgroups loop over tiles of T lines.
 // ------------------------------------------------------------------------------
+#ifndef VPS_XPIPE_MIN_NC
+#define VPS_XPIPE_MIN_NC 2048
+#endif
 struct XParams {
   const cf* in;            // component 0
   const cf* in1;           // components 1, 2 of a vector field (binning modes, ncomp > 1)
@@ -863,6 +902,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   typedef PlanInfo<NC> PI;
   constexpr int L = PI::L, RL = PI::RL, NT = T * L;
   constexpr int H = RL / 2;   // |kx| values per lane on the FAST path
+  constexpr bool PIPE = (MODE == 0) && (NC >= VPS_XPIPE_MIN_NC);   // request the next line before transforming this one
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // carve: thr (double, nbins+2 with a +inf sentinel) | hsum (double) | tw | line buffers | hcnt
   double* thr = reinterpret_cast<double*>(smem_raw);
@@ -940,7 +980,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
       }
     }
   };
-  auto load_line = [&](int c, int l) {   // l: the lane index (callers inside loops pass an opaque copy)
+  auto load_line = [&](cf (&v)[RL], int c, int l) {   // l: the lane index (callers inside loops pass an opaque copy)
     constexpr int R = PI::R0, NB = RL / R;
     const cf* base = (c == 0 ? p.in : (c == 1 ? p.in1 : p.in2)) + li * p.seglen;
 #pragma unroll
@@ -967,7 +1007,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   };
   if ((long long)blockIdx.x < ntiles) {
     locate_line(blockIdx.x);
-    load_line(0, l);
+    load_line(v, 0, l);
   }
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // line bookkeeping of THIS tile (v already holds, or is receiving, its inputs)
@@ -1012,18 +1052,40 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
         int lc = l;
         asm volatile("" : "+v"(lc));
         lc = (L & (L - 1)) == 0 ? (lc & (L - 1)) : lc % L;   // give the value range back to the compiler (address folding needs it)
-        exchange_sync<WSYNC>();  // previous readers are done with the line buffers
-        fft_from_regs<NC, WSYNC>(v, line, tw, lc);
+        if constexpr (PIPE) {
+          // Longest lines: LDS allows two waves per SIMD, so registers are plentiful -- the NEXT transform's inputs (next
+          // component of this tile, or the first of the next tile) are requested before this one starts and arrive
+          // while it runs, instead of being waited for right after being issued.
+          cf w[RL];
+          if (c + 1 < p.ncomp) {
+            load_line(w, c + 1, lc);
+          } else if (tile + gridDim.x < ntiles) {
+            locate_line(tile + gridDim.x);
+            load_line(w, 0, lc);
+          }
+          exchange_sync<WSYNC>();  // previous readers are done with the line buffers
+          fft_from_regs<NC, WSYNC>(v, line, tw, lc);
 #pragma unroll
-        for (int i = 0; i < RL; ++i) {
-          const float a = v[i].x * v[i].x + v[i].y * v[i].y;
-          pacc[i] = (c == 0) ? a : pacc[i] + a;
-        }
-        if (c + 1 < p.ncomp) {
-          load_line(c + 1, lc);
-        } else if (tile + gridDim.x < ntiles) {
-          locate_line(tile + gridDim.x);
-          load_line(0, lc);
+          for (int i = 0; i < RL; ++i) {
+            const float a = v[i].x * v[i].x + v[i].y * v[i].y;
+            pacc[i] = (c == 0) ? a : pacc[i] + a;
+          }
+#pragma unroll
+          for (int i = 0; i < RL; ++i) v[i] = w[i];
+        } else {
+          exchange_sync<WSYNC>();  // previous readers are done with the line buffers
+          fft_from_regs<NC, WSYNC>(v, line, tw, lc);
+#pragma unroll
+          for (int i = 0; i < RL; ++i) {
+            const float a = v[i].x * v[i].x + v[i].y * v[i].y;
+            pacc[i] = (c == 0) ? a : pacc[i] + a;
+          }
+          if (c + 1 < p.ncomp) {
+            load_line(v, c + 1, lc);
+          } else if (tile + gridDim.x < ntiles) {
+            locate_line(tile + gridDim.x);
+            load_line(v, 0, lc);
+          }
         }
       }
       float* pw = reinterpret_cast<float*>(line);
@@ -1142,7 +1204,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
     if constexpr (MODE != 0) {
       if (tile + gridDim.x < ntiles) {
         locate_line(tile + gridDim.x);
-        load_line(0, l);
+        load_line(v, 0, l);
       }
     }
   }
@@ -1600,7 +1662,7 @@ static int fft_y_of(vps_ctx* ctx, int N, int nx, const cf* B, const cf* BN, void
   return rc;
 }
 
-int vps_pencil_tp(void) { return PENCIL_TP; }
+int vps_pencil_tp(int N) { return N / 2 >= 1024 ? VPS_PENCIL_TP_LONG : 16; }   // = pencil_tp<N/2>()
 
 bool vps_pencil_supported(vps_ctx* ctx, int N) {
   if (!vps_fft_supported(N) || N < 64 || N > 2048) return false;
@@ -1624,7 +1686,7 @@ int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, cons
   p.start = start;
   p.N = N;
   p.nx = nx;
-  p.nby = N / PENCIL_TP;
+  p.nby = N / vps_pencil_tp(N);
   p.ncomp = ncomp;
   for (int c = 0; c < 3; ++c) {
     p.chan[c] = chan[c < ncomp ? c : 0];

@@ -92,7 +92,7 @@ struct vps_launch_timer {
 int vps_fft_get_tables(vps_ctx* ctx, int NC, vps_fft_tables* out);
 void vps_fft_free_tables(vps_ctx* ctx);
 // fused deposit -> z pass ("pencil" path): records sorted by pencil -> ncomp half spectra
-int vps_pencil_tp(void);
+int vps_pencil_tp(int N);
 bool vps_pencil_supported(vps_ctx* ctx, int N);
 int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, const unsigned* start,
                       int ncomp, const int* chan, int divide, int energy, float vol, void* spec_dev, void* nyq_dev,

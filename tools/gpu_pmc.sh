@@ -5,7 +5,7 @@
 tag=$1; ctrs=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/prof
-rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/prof/${tag}_pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 "$@" > gpurun_out/prof/${tag}_pmc.log 2>&1
+rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/prof/${tag}_pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-other-configs --profile-steps 1 "$@" > gpurun_out/prof/${tag}_pmc.log 2>&1
 f=$(ls gpurun_out/prof/${tag}_pmc/*/*_counter_collection.csv | head -1)
 python3 - "$f" $ctrs <<'PY'
 import csv,sys,re
