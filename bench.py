@@ -147,7 +147,9 @@ class Workload:
         maxc = max(NCOMP[q] for q in self.quantities)
         if route == "ngp":
             self.fused = (not unfused) and all(K.fused_supported(N, device.QUANTITY[q]) for q in self.quantities)
-            if self.fused:
+            if self.fused and self.pipe.chunked:
+                self.zimg = K.empty((maxc, K.zimage_elems(N, nx)), torch.complex64)
+            elif self.fused:
                 self.spec = K.empty((maxc, N // 2, N, nx), torch.complex64)
                 self.nyq = K.empty((maxc, N, nx), torch.complex64)
             else:
@@ -190,7 +192,12 @@ class Workload:
             for q in self.quantities:
                 qi, nc = dev.QUANTITY[q], NCOMP[q]
                 self.acc_buf.zero_()
-                if self.fused:
+                if self.fused and self.pipe.chunked:
+                    # several ranks: the fused kernel stops after the z pass; y pass, exchange and x pass run chunk by chunk
+                    z = K.deposit_fft_z(self.pos, self.vel, self.rho, N, L, x0, nx, qi, zimg=self.zimg[:nc], reuse_sort=token)
+                    token = K.fused_token()
+                    self.pipe.accumulate_zimages([z[i] for i in range(nc)], self.psum, self.nsample)
+                elif self.fused:
                     # deposit + field algebra + z pass in one kernel (pencil buckets), then the y passes;
                     # the second and third quantity of a step reuse the first one's bucket sort
                     spec, nyq = K.deposit_fft_zy(self.pos, self.vel, self.rho, N, L, x0, nx, qi,
@@ -310,6 +317,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
         data = "synthetic"
     wl = Workload(K, comm, N, L, route, quantities, flavour, dpos, dvel, drho, unfused=args.unfused)
     nx = wl.nx
+    nchunks = wl.pipe.nchunks
     nkz, nky, NH = N // 2 // G, N // G, N // 2
     nfields = wl.fields_per_step()
 
@@ -342,8 +350,11 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     K.timing(False)
     nst = max(profile_steps, 1)
     step_kernel_ms = {k: v[1] / nst for k, v in tim.items() if v[0]}
-    # y and x launches alternate main / Nyquist-plane; the main launch is the big one
-    main = {"fft_y": per["fft_y"][0::2], "fft_x": per["fft_x"][0::2], "fft_z": per["fft_z"], "nn_query": per["nn_query"]}
+    # y and x launches come as main launches (whole fields, or kz chunks of them) and small Nyquist-plane launches
+    # (one plane against hundreds): the main ones are those within a factor 8 of the longest
+    def main_of(v):
+        return v[v * 8.0 >= v.max()] if len(v) else v
+    main = {"fft_y": main_of(per["fft_y"]), "fft_x": main_of(per["fft_x"]), "fft_z": per["fft_z"], "nn_query": per["nn_query"]}
     Nps = Np / G      # particles inside one rank's slab (uniform positions)
     # algorithmic HBM bytes of the main launches of ONE step, per kernel family (DESIGN.md "Kernels")
     step_bytes = {"fft_y": nfields * 16.0 * nx * N * NH, "fft_x": nfields * 8.0 * nkz * N * N}
@@ -381,8 +392,8 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
                    "deviation": ("strong-scaled over %d GPU(s) of one node" % world) if cfg in ("C4", "C5") and world != 8 else None,
                    "grid": N, "particles": Np, "route": route, "quantities": list(quantities),
                    "scalar_fields_per_step": nfields, "path": wl.describe_path(),
-                   "parallelism": ("x-slab x%d, 1 all-to-all/field (+1 small one for the Nyquist plane)" % world)
-                   if G == world else ("EMULATED rank 0 of %d on one GPU, exchanges skipped (diagnostic)" % G)},
+                   "parallelism": ("x-slab x%d, one message per field and pair of ranks in %d kz chunks (Nyquist rows inside it)"
+                                   % (world, nchunks)) if (G == world and world > 1) else "one GPU, no exchange" if G == world else ("EMULATED rank 0 of %d on one GPU, exchanges skipped (diagnostic)" % G)},
         "data": data,
         "particles_per_s": Np / (grid_ms * 1e-3) if grid_ms > 0 else None,
         "gridding_note": ("bucket sort only: the LDS accumulation of the fused path lives in the fft_z launch"

@@ -213,6 +213,29 @@ int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev,
 int vps_fft_zy_weighted(vps_ctx* ctx, int N, int nx, const float* field_dev, const float* weight_dev,
                         void* spec_dev, void* nyq_dev, void* work_dev);
 
+/* The same two passes as separate calls, for the chunked slab exchange of several ranks (G = number of x-slabs):
+ *   vps_fft_z          z pass of field_dev (* weight_dev if not NULL) into a z image zimg_dev
+ *                      (vps_fft_zimage_bytes(N, nx) bytes: B[x][kz][y], kz < N/2, followed by the Nyquist plane BN[x][y]);
+ *   vps_deposit_fft_z  the fused deposit + field algebra + z pass of vps_deposit_fft_zy, stopping there: ncomp z images
+ *                      (3: velocity / momentum, 1: energy) in zimg_dev; work_dev: vps_deposit_fft_z_workspace_bytes;
+ *   vps_fft_y          y pass of chunk `chunk` of `nchunks` of a z image: rank h's kz rows
+ *                      h*nkz + chunk*nkc .. + nkc (nkz = N/2/G, nkc = nkz/nchunks) are transformed and written as ONE
+ *                      send buffer for an equal-split all-to-all, out_dev = [h][ F_zy[kz][ky][x] (nkc*N*nx) |
+ *                      -- last chunk only -- Nyquist rows F_zy[N/2][ky in rank h's N/G rows][x] (N/G*nx) ],
+ *                      vps_fft_y_chunk_elems(...) complex64 elements in all.  After the exchange the buffer received
+ *                      from rank g is that layout with x running over g's slab: vps_fft_x / vps_fft_x_bin read it with
+ *                      nseg = G, seg_stride = one block (and the Nyquist lines at offset nkc*N*nx of the blocks).
+ * This replaces the four allgathers per buffer flush of scripts/parallel_optimized.py:365-368 with one message per
+ * scalar field (or several chunks of it, so that the exchange of one chunk overlaps the passes of its neighbours). */
+size_t vps_fft_zimage_bytes(int N, int nx);
+int vps_fft_z(vps_ctx* ctx, int N, int nx, const float* field_dev, const float* weight_dev, void* zimg_dev);
+size_t vps_deposit_fft_z_workspace_bytes(int64_t np, int N, int nx);
+int vps_deposit_fft_z(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
+                      const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx,
+                      int quantity, int flags, void* zimg_dev, void* work_dev);
+int64_t vps_fft_y_chunk_elems(int N, int nx, int G, int nchunks, int chunk);   /* -1: G, nchunks do not divide */
+int vps_fft_y(vps_ctx* ctx, int N, int nx, const void* zimg_dev, int G, int nchunks, int chunk, void* out_dev);
+
 /* x pass over `nlines` lines of length N.  Line i is made of nseg segments of
  * N/nseg contiguous complex64: element x of line i lives at
  *   in_dev[(x / seglen) * seg_stride + i * seglen + (x % seglen)],  seglen = N/nseg

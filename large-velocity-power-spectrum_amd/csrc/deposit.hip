@@ -976,15 +976,42 @@ size_t vps_deposit_fft_zy_workspace_bytes(int64_t np, int N, int nx) {
   return sort + images;
 }
 
+static int deposit_fft_impl(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
+                            const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx, int quantity,
+                            int flags, void* spec_dev, void* nyq_dev, void* zimg_dev, void* work_dev);
+
 int vps_deposit_fft_zy(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
                        const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx, int quantity,
                        int flags, void* spec_dev, void* nyq_dev, void* work_dev) {
   VPS_ENTER(ctx);
+  if (!spec_dev || !nyq_dev) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_fft_zy: null buffer");
+  return deposit_fft_impl(ctx, pos_dev, pos_is_f64, vel_dev, rho_dev, np, N, Lbox, x0, nx, quantity, flags, spec_dev,
+                          nyq_dev, nullptr, work_dev);
+}
+
+size_t vps_deposit_fft_z_workspace_bytes(int64_t np, int N, int nx) {
+  if (np < 0 || N < 16 || nx < 1) return 0;
+  return dep_layout(np, 4, make_pencils(N, 0, nx, vps_pencil_tp(N))).total;
+}
+
+int vps_deposit_fft_z(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
+                      const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx, int quantity,
+                      int flags, void* zimg_dev, void* work_dev) {
+  VPS_ENTER(ctx);
+  if (!zimg_dev) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_fft_z: null buffer");
+  return deposit_fft_impl(ctx, pos_dev, pos_is_f64, vel_dev, rho_dev, np, N, Lbox, x0, nx, quantity, flags, nullptr,
+                          nullptr, zimg_dev, work_dev);
+}
+
+// zimg_dev != NULL: stop after the z pass, the images [component][B | BN] go to zimg_dev (work_dev then only holds the sort)
+static int deposit_fft_impl(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
+                            const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx, int quantity,
+                            int flags, void* spec_dev, void* nyq_dev, void* zimg_dev, void* work_dev) {
   int rc = check_deposit_args(ctx, "vps_deposit_fft_zy", np, N, Lbox, x0, nx);
   if (rc) return rc;
   if (!vps_deposit_fft_zy_supported(ctx, N, quantity))
     return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_deposit_fft_zy: N=%d quantity=%d not supported by the fused path", N, quantity);
-  if (!spec_dev || !nyq_dev || !work_dev || (np > 0 && (!pos_dev || !vel_dev || !rho_dev)))
+  if (!work_dev || (np > 0 && (!pos_dev || !vel_dev || !rho_dev)))
     return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_fft_zy: null buffer");
   const Bricks b = make_pencils(N, x0, nx, vps_pencil_tp(N));
   char* work = reinterpret_cast<char*>(work_dev);
@@ -1002,8 +1029,7 @@ int vps_deposit_fft_zy(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const 
   return vps_fft_pencil_zy(ctx, N, nx, reinterpret_cast<const unsigned*>(work + l.records),
                            reinterpret_cast<const unsigned*>(work + l.start), 3, chan,
                            quantity == VPS_MOMENTUM ? 0 : 1, quantity == VPS_ENERGY ? 1 : 0, (float)(lc * lc * lc),
-                           spec_dev, nyq_dev,
-                           work + l.total);
+                           spec_dev, nyq_dev, zimg_dev ? zimg_dev : (void*)(work + l.total));
 }
 
 int vps_density_velocity_vector(vps_ctx* ctx, const float* vel_dev, const float* rho_dev, int64_t np,

@@ -472,6 +472,15 @@ struct PassParams {
   int A, B;                  // extent of tile axis / batch axis
   const cf* tw_stage;
   const cf* tw_r2c;
+  // Chunked slab exchange (vps_fft_y): the B batches of a launch are `bg`-row groups, one per destination rank --
+  // launch batch b reads input batch (b / bg) * bg_in + b_off + b % bg and its output starts bg_gap elements later per
+  // group (room for the Nyquist rows that ride behind a destination's last chunk).  bg = 0: plain batches.
+  int bg, b_off;
+  long long bg_in, bg_gap;
+  // the Nyquist-plane launch (B = 1): output row k moves by (k / kg) * kg_gap elements (kg = 0: none), so that each
+  // destination's rows land behind that destination's block
+  int kg;
+  long long kg_gap;
 };
 
 // Non-temporal (streaming) access to one complex value: data that is written once for the next pass
@@ -558,8 +567,10 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
       bid = base + G * (h % 8) + (h / 8);
     }
   }
-  const int b = bid / tiles;
+  const int bo = bid / tiles;                 // batch as the output sees it
   const int a0 = (bid % tiles) * T;
+  const long long b = p.bg ? (long long)(bo / p.bg) * p.bg_in + p.b_off + bo % p.bg : bo;   // batch as the input sees it
+  const long long ogap = p.bg ? (long long)(bo / p.bg) * p.bg_gap : 0;
 
   if constexpr (PI::TWLDS)
     for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
@@ -614,7 +625,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
   for (int i = 0; i < RL; ++i) buf[tridx<T>(out_index<NC>(l, i), t)] = v[i];
   __syncthreads();
 
-  cf* out = reinterpret_cast<cf*>(p.out) + (long long)b * p.out_ob + a0;
+  cf* out = reinterpret_cast<cf*>(p.out) + (long long)bo * p.out_ob + ogap + a0;
   if constexpr (!REAL) {
 #pragma unroll 4
     for (int i = 0; i < RL; ++i) {
@@ -622,10 +633,11 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
       const int tt = idx % T, k = idx / T;
       if (a0 + tt < p.A) {
         const cf val = buf[tridx<T>(k, tt)];
+        const long long o = (long long)k * p.out_ok + (p.kg ? (long long)(k / p.kg) * p.kg_gap : 0) + tt;
         if constexpr (NTEMP)
-          store_stream(&out[(long long)k * p.out_ok + tt], val);
+          store_stream(&out[o], val);
         else
-          out[(long long)k * p.out_ok + tt] = val;
+          out[o] = val;
       }
     }
   } else {
@@ -1594,21 +1606,11 @@ int vps_fft_zy(vps_ctx* ctx, int N, int nx, const float* field_dev, void* spec_d
   return vps_fft_zy_weighted(ctx, N, nx, field_dev, nullptr, spec_dev, nyq_dev, work_dev);
 }
 
-int vps_fft_zy_weighted(vps_ctx* ctx, int N, int nx, const float* field_dev, const float* weight_dev,
-                        void* spec_dev, void* nyq_dev, void* work_dev) {
-  VPS_ENTER(ctx);
-  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
-  if (nx < 1 || nx > N) return vps_fail(ctx, VPS_ERR_ARG, "nx=%d out of range", nx);
-  if (!field_dev || !spec_dev || !nyq_dev || !work_dev) return vps_fail(ctx, VPS_ERR_ARG, "null buffer");
+static int fft_z_of(vps_ctx* ctx, int N, int nx, const float* field_dev, const float* weight_dev, cf* B, cf* BN) {
   const int NH = N / 2;
-  vps_fft_tables tz, ty;
+  vps_fft_tables tz;
   int rc = vps_fft_get_tables(ctx, NH, &tz);
   if (rc) return rc;
-  rc = vps_fft_get_tables(ctx, N, &ty);
-  if (rc) return rc;
-  cf* B = reinterpret_cast<cf*>(work_dev);
-  cf* BN = B + (size_t)nx * NH * N;
-
   // z pass: lines (a = y, b = x) of R[x][y][:] -> B[x][kz][y], BN[x][y]
   PassParams pz{};
   pz.in = field_dev;
@@ -1624,11 +1626,86 @@ int vps_fft_zy_weighted(vps_ctx* ctx, int N, int nx, const float* field_dev, con
   pz.B = nx;
   pz.tw_stage = tz.tw_stage;
   pz.tw_r2c = tz.tw_r2c;
-  rc = route_transpose(ctx, NH, 1, pz, VPS_K_FFT_Z);
-  if (rc) return rc;
+  return route_transpose(ctx, NH, 1, pz, VPS_K_FFT_Z);
+}
 
+int vps_fft_zy_weighted(vps_ctx* ctx, int N, int nx, const float* field_dev, const float* weight_dev,
+                        void* spec_dev, void* nyq_dev, void* work_dev) {
+  VPS_ENTER(ctx);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
+  if (nx < 1 || nx > N) return vps_fail(ctx, VPS_ERR_ARG, "nx=%d out of range", nx);
+  if (!field_dev || !spec_dev || !nyq_dev || !work_dev) return vps_fail(ctx, VPS_ERR_ARG, "null buffer");
+  cf* B = reinterpret_cast<cf*>(work_dev);
+  cf* BN = B + (size_t)nx * (N / 2) * N;
+  int rc = fft_z_of(ctx, N, nx, field_dev, weight_dev, B, BN);
+  if (rc) return rc;
   // y pass: lines (a = x, b = kz) of B[x][kz][:] -> C[kz][ky][x]; Nyquist plane BN[x][:] -> CN[ky][x]
   return fft_y_of(ctx, N, nx, B, BN, spec_dev, nyq_dev);
+}
+
+// ---- the split form for the chunked slab exchange: z pass into an image, y pass one kz chunk at a time ----
+size_t vps_fft_zimage_bytes(int N, int nx) { return vps_fft_workspace_bytes(N, nx); }
+
+int vps_fft_z(vps_ctx* ctx, int N, int nx, const float* field_dev, const float* weight_dev, void* zimg_dev) {
+  VPS_ENTER(ctx);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_fft_z: unsupported N=%d", N);
+  if (nx < 1 || nx > N) return vps_fail(ctx, VPS_ERR_ARG, "nx=%d out of range", nx);
+  if (!field_dev || !zimg_dev) return vps_fail(ctx, VPS_ERR_ARG, "null buffer");
+  cf* B = reinterpret_cast<cf*>(zimg_dev);
+  return fft_z_of(ctx, N, nx, field_dev, weight_dev, B, B + (size_t)nx * (N / 2) * N);
+}
+
+int64_t vps_fft_y_chunk_elems(int N, int nx, int G, int nchunks, int chunk) {
+  if (G < 1 || nchunks < 1 || chunk < 0 || chunk >= nchunks || N % G || (N / 2) % (G * nchunks)) return -1;
+  const int64_t nkc = N / 2 / G / nchunks;
+  return (int64_t)G * (nkc * N * nx + (chunk == nchunks - 1 ? (int64_t)(N / G) * nx : 0));
+}
+
+int vps_fft_y(vps_ctx* ctx, int N, int nx, const void* zimg_dev, int G, int nchunks, int chunk, void* out_dev) {
+  VPS_ENTER(ctx);
+  if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_fft_y: unsupported N=%d", N);
+  if (nx < 1 || nx > N || !zimg_dev || !out_dev) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_y: bad nx / null buffer");
+  if (vps_fft_y_chunk_elems(N, nx, G, nchunks, chunk) < 0)
+    return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_y: G=%d ranks x %d chunks must divide N/2=%d (and G divide N)", G, nchunks, N / 2);
+  const int NH = N / 2, nkz = NH / G, nkc = nkz / nchunks, nky = N / G;
+  const bool last = chunk == nchunks - 1;
+  vps_fft_tables ty;
+  int rc = vps_fft_get_tables(ctx, N, &ty);
+  if (rc) return rc;
+  const cf* B = reinterpret_cast<const cf*>(zimg_dev);
+  const cf* BN = B + (size_t)nx * NH * N;
+  const long long blk = (long long)nkc * N * nx + (last ? (long long)nky * nx : 0);   // one destination's block
+  // kz rows {h nkz + chunk nkc + j}: launch batch b = h nkc + j
+  PassParams py{};
+  py.in = B;
+  py.out = out_dev;
+  py.in_sa = (long long)NH * N;
+  py.in_sb = N;
+  py.out_ob = (long long)N * nx;
+  py.out_ok = nx;
+  py.A = nx;
+  py.B = G * nkc;
+  py.tw_stage = ty.tw_stage;
+  py.bg = nkc;
+  py.b_off = chunk * nkc;
+  py.bg_in = nkz;
+  py.bg_gap = last ? (long long)nky * nx : 0;
+  rc = route_transpose(ctx, N, 0, py, VPS_K_FFT_Y);
+  if (rc || !last) return rc;
+  // Nyquist plane: ky rows of destination h go behind that destination's kz rows
+  PassParams pn{};
+  pn.in = BN;
+  pn.out = reinterpret_cast<cf*>(out_dev) + (long long)nkc * N * nx;
+  pn.in_sa = N;
+  pn.in_sb = 0;
+  pn.out_ob = 0;
+  pn.out_ok = nx;
+  pn.A = nx;
+  pn.B = 1;
+  pn.tw_stage = ty.tw_stage;
+  pn.kg = nky;
+  pn.kg_gap = blk - (long long)nky * nx;
+  return route_transpose(ctx, N, 0, pn, VPS_K_FFT_Y);
 }
 
 }  // extern "C"
@@ -1671,7 +1748,8 @@ bool vps_pencil_supported(vps_ctx* ctx, int N) {
   return (size_t)lds <= ctx->lds_per_cu;
 }
 
-// records sorted by pencil -> ncomp half spectra after the z and y passes
+// records sorted by pencil -> ncomp half spectra after the z and y passes (spec_dev == NULL: z pass only, the
+// z images [component][B | BN] stay in bwork_dev)
 int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, const unsigned* start,
                       int ncomp, const int* chan, int divide, int energy, float vol, void* spec_dev, void* nyq_dev,
                       void* bwork_dev) {
@@ -1700,7 +1778,7 @@ int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, cons
   p.tw_r2c = tz.tw_r2c;
   const long long npencils = (long long)nx * p.nby;
   rc = route_pencil(ctx, NH, p, npencils);
-  if (rc) return rc;
+  if (rc || !spec_dev) return rc;
   cf* spec = reinterpret_cast<cf*>(spec_dev);
   cf* nyq = reinterpret_cast<cf*>(nyq_dev);
   const int nout = energy ? 1 : ncomp;

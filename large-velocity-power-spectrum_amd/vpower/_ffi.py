@@ -62,6 +62,13 @@ SYMBOLS = (
     ("vps_fft_workspace_bytes", C.c_size_t, (C.c_int, C.c_int)),
     ("vps_fft_zy", C.c_int, (_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp)),
     ("vps_fft_zy_weighted", C.c_int, (_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp)),
+    ("vps_fft_zimage_bytes", C.c_size_t, (C.c_int, C.c_int)),
+    ("vps_fft_z", C.c_int, (_vp, C.c_int, C.c_int, _vp, _vp, _vp)),
+    ("vps_deposit_fft_z_workspace_bytes", C.c_size_t, (_i64, C.c_int, C.c_int)),
+    ("vps_deposit_fft_z", C.c_int, (_vp, _vp, C.c_int, _vp, _vp, _i64, C.c_int, C.c_double, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, _vp, _vp)),
+    ("vps_fft_y_chunk_elems", _i64, (C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)),
+    ("vps_fft_y", C.c_int, (_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp)),
     ("vps_fft_x", C.c_int, (_vp, C.c_int, _i64, _i64, C.c_int, _vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp)),
     ("vps_fft_x_bin", C.c_int, (_vp, C.c_int, _i64, _i64, C.c_int, C.POINTER(_vp), C.c_int, C.c_int, _i64, C.c_int,
                                _vp, _vp)),

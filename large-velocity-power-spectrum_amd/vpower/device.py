@@ -7,10 +7,11 @@ streams and (for more than one GPU) `torch.distributed` collectives.
 Multi-GPU: 1-D slab decomposition along x, one process per GPU.  Particles are
 replicated (as the reference replicates the snapshot on every MPI rank,
 scripts/parallel_optimized.py:272-276); each rank deposits / resamples its own x-slab,
-runs the z and y passes locally, exchanges the half spectrum with ONE all-to-all per
-scalar field (plus a small one for the Nyquist plane), runs the x pass with fused
-binning on its kz-slab and finally all-reduces the (nbins,) shell sums -- the step that
-replaces the two comm.Reduce calls at scripts/parallel_optimized.py:455-456.
+runs the z pass locally, then per kz chunk the y pass straight into the send buffer of an
+all-to-all (ONE message per scalar field and pair of ranks, the Nyquist-plane rows riding
+behind the last chunk; the chunks only pipeline it against the passes), runs the x pass
+with fused binning on the arrived chunks and finally all-reduces the (nbins,) shell sums --
+the step that replaces the two comm.Reduce calls at scripts/parallel_optimized.py:455-456.
 
 The kernel set is injectable so that the distributed choreography can be exercised on
 CPU tensors by the test-suite's oracle-backed stand-in; the product default is
@@ -364,6 +365,56 @@ class HipKernels:
                                                self._ptr(work)))
         return spec, nyq
 
+    # -- split form for the chunked slab exchange --------------------------------
+    def zimage_elems(self, N, nx):
+        return int(self.lib.vps_fft_zimage_bytes(int(N), int(nx))) // 8
+
+    def fft_z(self, field, N, nx, weight=None, zimg=None):
+        """z pass only: field [nx,N,N] float32 (* weight) -> z image (flat complex64: B[x][kz][y] | BN[x][y])."""
+        self._stream()
+        if zimg is None:
+            zimg = self.empty((self.zimage_elems(N, nx),), torch.complex64)
+        self._chk(self.lib.vps_fft_z(self.ctx, N, nx, self._ptr(field, torch.float32), self._ptr(weight, torch.float32),
+                                     self._ptr(zimg, torch.complex64)))
+        return zimg
+
+    def deposit_fft_z(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, zimg=None, reuse_sort=None):
+        """Fused deposit + field algebra + z pass -> z images [ncomp, zimage_elems] (ncomp = 1 for ENERGY, else 3)."""
+        self._stream()
+        ncomp = 1 if quantity == ENERGY else 3
+        if zimg is None:
+            zimg = self.empty((ncomp, self.zimage_elems(N, nx)), torch.complex64)
+        work = self.workspace("fused_z", self.lib.vps_deposit_fft_z_workspace_bytes(pos.shape[0], N, nx))
+        state = (weakref.ref(pos), weakref.ref(vel), weakref.ref(rho), pos._version, vel._version, rho._version,
+                 int(N), float(Lbox), int(x0), int(nx), work.data_ptr())
+        last = getattr(self, "_fused_token", None)
+        if (reuse_sort is not None and reuse_sort is last
+                and all(r() is t for r, t in zip(last[:3], (pos, vel, rho))) and last[3:] == state[3:]):
+            flags |= FLAG_REUSE_SORT
+        self._fused_token = state
+        self._chk(self.lib.vps_deposit_fft_z(self.ctx, self._ptr(pos), self._pos_kind(pos),
+                                             self._ptr(vel, torch.float32), self._ptr(rho, torch.float32),
+                                             pos.shape[0], N, float(Lbox), x0, nx, quantity, flags,
+                                             self._ptr(zimg, torch.complex64), self._ptr(work)))
+        return zimg
+
+    def y_chunk_elems(self, N, nx, G, nchunks, chunk):
+        n = int(self.lib.vps_fft_y_chunk_elems(int(N), int(nx), int(G), int(nchunks), int(chunk)))
+        if n < 0:
+            raise _ffi.VpsError("%d ranks x %d chunks do not divide N/2 = %d" % (G, nchunks, N // 2))
+        return n
+
+    def fft_y_chunk(self, zimg, N, nx, G, nchunks, chunk, out=None):
+        """y pass of one kz chunk of a z image -> the send buffer of an equal-split all-to-all over G ranks:
+        [h][ F_zy[kz in h's chunk rows][ky][x] | (last chunk) Nyquist rows of h ] (flat complex64)."""
+        self._stream()
+        n = self.y_chunk_elems(N, nx, G, nchunks, chunk)
+        if out is None:
+            out = self.empty((n,), torch.complex64)
+        self._chk(self.lib.vps_fft_y(self.ctx, N, nx, self._ptr(zimg, torch.complex64), G, nchunks, chunk,
+                                     self._ptr(out, torch.complex64)))
+        return out
+
     def fft_x_bin(self, lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True):
         """x pass + shell sums into psum; with `count` also the shell counts into nsample."""
         self._stream()
@@ -543,6 +594,56 @@ class PowerPipeline:
         spacing = (self.edges[-1] - self.edges[0]) / self.nbins
         self._binning = (self.N, self.k2, self.thr, float(self.edges[0]), 1.0 / spacing)
         self.const = (self.Lbox / (2 * np.pi)) ** 1.5 / self.N ** 3   # interp.py:1381
+        # Several ranks: every scalar field crosses the node as ONE message per pair of ranks (its kz rows with the
+        # Nyquist-plane rows riding behind them), cut into `nchunks` kz chunks so that the exchange of a chunk
+        # overlaps the y pass of the next and the x pass of the previous one.
+        self.chunked = G > 1 or self.comm.force or os.environ.get("VPS_CHUNKED") == "1"
+        self.nchunks = self._pick_chunks()
+
+    def _pick_chunks(self):
+        """kz chunks per field: VPS_A2A_CHUNKS (default 4), lowered until it divides the rank's kz rows and a
+        chunk's pair message stays above 2 MiB (smaller messages are latency-bound on xGMI)."""
+        G = self.comm.world
+        nkz = self.N // 2 // G
+        try:
+            c = max(1, int(os.environ.get("VPS_A2A_CHUNKS", "4")))
+        except ValueError:
+            c = 4
+        c = min(c, nkz)
+        while c > 1 and (nkz % c or (os.environ.get("VPS_A2A_CHUNKS") is None
+                                     and nkz // c * self.N * self.nx * 8 < (2 << 20))):
+            c -= 1
+        return max(c, 1)
+
+    def accumulate_zimages(self, zimgs, psum=None, nsample=None, count=True):
+        """x-side of the transform for z images (HipKernels.fft_z / deposit_fft_z): per kz chunk, y pass into the
+        send buffer, all-to-all started at once, then -- as chunks arrive -- x pass + shell sums.  Up to three
+        components share one binning launch per chunk (their |F|^2 are summed before the shell search)."""
+        N, nx, G, r = self.N, self.nx, self.comm.world, self.comm.rank
+        k = self.k
+        k.set_binning(*self._binning)
+        if psum is None:
+            psum, nsample = self.new_accumulators()
+        C_ = self.nchunks
+        nkz, nky = N // 2 // G, N // G
+        nkc = nkz // C_
+        group = 1 if os.environ.get("VPS_X_PER_COMPONENT") == "1" else 3
+        for i in range(0, len(zimgs), group):
+            comps = zimgs[i:i + group]
+            cnt = count and i == 0
+            pending = []
+            for c in range(C_):                      # y passes and exchanges are issued chunk by chunk ...
+                pending.append([self.comm.all_to_all_start(k.fft_y_chunk(z, N, nx, G, C_, c)) for z in comps])
+            for c in range(C_):                      # ... and binned in the same order, as they complete
+                recvs = [self.comm.all_to_all_finish(h) for h in pending[c]]
+                pending[c] = None
+                last = c == C_ - 1
+                blk = nkc * N * nx + (nky * nx if last else 0)
+                k.fft_x_bin_multi(recvs, N, nkc * N, 0, r * nkz + c * nkc, G, blk, psum, nsample, count=cnt)
+                if last:
+                    nyqs = [t[nkc * N * nx:] for t in recvs]
+                    k.fft_x_bin_multi(nyqs, N, nky, r * nky, N // 2, G, blk, psum, nsample, count=cnt)
+        return psum, nsample
 
     # -- stage B + C on one or more real fields of this rank's slab ---------------
     def accumulate(self, fields, psum=None, nsample=None, count=True, weight=None):
@@ -555,10 +656,12 @@ class PowerPipeline:
         k.set_binning(*self._binning)
         if psum is None:
             psum, nsample = self.new_accumulators()
+        if self.chunked:
+            zimgs = [k.fft_z(f, N, nx, weight=weight) for f in fields]
+            return self.accumulate_zimages(zimgs, psum, nsample, count)
         nkz = N // 2 // G      # kz rows per rank after the exchange
         nky = N // G           # Nyquist-plane ky rows per rank
-        # issue every field's z/y passes and start its exchange right away, then run the x
-        # passes as the exchanges complete: communication overlaps the neighbouring fields' compute
+        # one rank: no exchange -- z/y passes of every field, then the x passes
         pending = []
         for f in fields:
             spec, nyq = k.fft_zy(f, N, nx) if weight is None else k.fft_zy(f, N, nx, weight=weight)
@@ -586,6 +689,9 @@ class PowerPipeline:
         """Like `accumulate`, for fields that already went through the z and y passes
         (spec [ncomp, N/2, N, nx], nyq [ncomp, N, nx], e.g. from HipKernels.deposit_fft_zy)."""
         N, nx, G, r = self.N, self.nx, self.comm.world, self.comm.rank
+        if self.chunked:
+            raise Exception("several ranks exchange z images chunk by chunk: use HipKernels.deposit_fft_z / fft_z "
+                            "and PowerPipeline.accumulate_zimages")
         k = self.k
         k.set_binning(*self._binning)
         if psum is None:

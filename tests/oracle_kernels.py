@@ -37,6 +37,35 @@ class OracleKernels:
         F = np.ascontiguousarray(F.transpose(2, 1, 0)).astype(np.complex64)   # [kz, ky, x]
         return torch.from_numpy(F[: N // 2].copy()), torch.from_numpy(F[N // 2].copy())
 
+    # -- split form: z image = [B[x][kz][y] (kz < N/2) | BN[x][y]] flat complex64 (include/vps_hip.h: vps_fft_z) --
+    def fft_z(self, field, N, nx, weight=None, zimg=None):
+        f = field.numpy().astype(np.float64)
+        if weight is not None:
+            f = f * weight.numpy().astype(np.float64)
+        Fz = np.fft.rfft(f, axis=2)                                   # [x, y, kz <= N/2]
+        B = np.ascontiguousarray(Fz[:, :, : N // 2].transpose(0, 2, 1)).astype(np.complex64)   # [x, kz, y]
+        BN = np.ascontiguousarray(Fz[:, :, N // 2]).astype(np.complex64)                        # [x, y]
+        return torch.from_numpy(np.concatenate((B.ravel(), BN.ravel())))
+
+    def fft_y_chunk(self, zimg, N, nx, G, nchunks, chunk, out=None):
+        """vps_fft_y: [h][ F_zy[kz in h's chunk rows][ky][x] | (last chunk) Nyquist rows ky in h's range ]."""
+        NH = N // 2
+        nkz, nky = NH // G, N // G
+        nkc = nkz // nchunks
+        assert nkc * nchunks == nkz
+        z = zimg.numpy()
+        B = z[: nx * NH * N].reshape(nx, NH, N).astype(np.complex128)
+        BN = z[nx * NH * N:].reshape(nx, N).astype(np.complex128)
+        Cy = np.fft.fft(B, axis=2).transpose(1, 2, 0)                 # [kz, ky, x]
+        CN = np.fft.fft(BN, axis=1).T                                 # [ky, x]
+        parts = []
+        for h in range(G):
+            k0 = h * nkz + chunk * nkc
+            parts.append(Cy[k0:k0 + nkc].ravel())
+            if chunk == nchunks - 1:
+                parts.append(CN[h * nky:(h + 1) * nky].ravel())
+        return torch.from_numpy(np.concatenate(parts).astype(np.complex64))
+
     def _lines(self, lines, N, nlines, nseg, seg_stride):
         flat = lines.numpy().reshape(-1)
         seglen = N // nseg

@@ -24,12 +24,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, L, seed, out_dir):
+def _worker(rank, world, port, N, L, seed, out_dir, chunks=None):
     for p in (ROOT, os.path.join(ROOT, "large-velocity-power-spectrum_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if chunks is not None:
+        os.environ["VPS_A2A_CHUNKS"] = str(chunks)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from vpower import device
@@ -38,6 +40,7 @@ def _worker(rank, world, port, N, L, seed, out_dir):
         fields = [rng.standard_normal((N, N, N)).astype(np.float32) for _ in range(3)]
         pipe = device.PowerPipeline(N, L, kernels=OracleKernels(), comm=device.SlabComm())
         assert pipe.comm.world == world and pipe.nx == N // world and pipe.x0 == rank * (N // world)
+        assert pipe.chunked and (chunks is None or pipe.nchunks == chunks)
         slabs = [torch.from_numpy(np.ascontiguousarray(f[pipe.x0: pipe.x0 + pipe.nx])) for f in fields]
         tab = pipe.spectrum(slabs)
         np.save(os.path.join(out_dir, f"tab_{rank}.npy"), tab)
@@ -58,3 +61,18 @@ def test_slab_pipeline_matches_oracle(tmp_path, world, N):
         assert np.allclose(tab[:, 2], ref[:, 2], rtol=1e-5)
         assert np.allclose(tab[:, 1], ref[:, 1], rtol=1e-5)
     assert np.array_equal(np.load(tmp_path / "tab_0.npy"), np.load(tmp_path / f"tab_{world - 1}.npy"))
+
+
+@pytest.mark.parametrize("world,N,chunks", [(2, 32, 2), (2, 32, 4), (4, 32, 4), (4, 64, 2)])
+def test_chunked_exchange_one_message_per_field(tmp_path, world, N, chunks):
+    """The kz-chunked pipeline (y pass of a chunk -> all-to-all of that chunk -> x pass of the arrived chunk, the
+    Nyquist-plane rows riding behind the last chunk of the same message) with more than one chunk per field."""
+    L, seed = 2.5, 5
+    mp.spawn(_worker, args=(world, _free_port(), N, L, seed, str(tmp_path), chunks), nprocs=world, join=True)
+    rng = np.random.default_rng(seed)
+    fields = [rng.standard_normal((N, N, N)).astype(np.float32).astype(np.float64) for _ in range(3)]
+    ref = orc.spectrum_table(orc.vector_power(*fields, L, N), L, N, "library")
+    for r in range(world):
+        tab = np.load(tmp_path / f"tab_{r}.npy")
+        assert np.array_equal(tab[:, 3], ref[:, 3])
+        assert np.allclose(tab[:, 2], ref[:, 2], rtol=1e-5)

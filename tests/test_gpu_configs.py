@@ -470,3 +470,52 @@ def test_nn_scatter_and_query_centric_kernels_agree(K, monkeypatch):
     pos64 = pos.astype(np.float64) * (1 + 1e-9)
     _, i5 = K.nn_resample(K.to_device(pos64), payload, (ax, ax, ax), 0, N, want_index=True)
     assert np.array_equal(i5.cpu().numpy().ravel(), orc.exact_nn_lattice(pos64, ax, ax, ax))
+
+
+# --------------------------------------------------- chunked exchange layout (one GPU) ----
+@pytest.mark.parametrize("N,G,C", [(64, 2, 1), (128, 4, 2), (128, 4, 4), (256, 8, 2), (500, 5, 2), (250, 5, 1)])
+def test_chunked_y_pass_layout_emulated_ranks(K, N, G, C):
+    """vps_fft_z + vps_fft_y with the real kernels: every emulated rank produces its send buffers chunk by chunk, the
+    all-to-all is played by slicing them, the x pass reads the received blocks (Nyquist rows behind the last chunk) --
+    the result must equal the one-rank transform of the same field."""
+    from vpower import device
+    rng = np.random.default_rng(N + G + C)
+    f = K.to_device(rng.standard_normal((N, N, N)).astype(np.float32))
+    pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=device.SlabComm(enabled=False))
+    ref = pipe.finish(*pipe.accumulate([f]))
+    nx, nkz, nky = N // G, N // 2 // G, N // G
+    nkc = nkz // C
+    zimgs = [K.fft_z(f[g * nx:(g + 1) * nx].contiguous(), N, nx) for g in range(G)]
+    psum, ns = K.zeros((pipe.nbins,), torch.float64), K.zeros((pipe.nbins,), torch.int64)
+    K.set_binning(*pipe._binning)
+    for c in range(C):
+        last = c == C - 1
+        blk = nkc * N * nx + (nky * nx if last else 0)
+        sends = [K.fft_y_chunk(zimgs[g], N, nx, G, C, c) for g in range(G)]
+        assert all(s_.numel() == G * blk for s_ in sends)
+        for h in range(G):
+            recv = torch.cat([sends[g][h * blk:(h + 1) * blk] for g in range(G)])
+            K.fft_x_bin(recv, N, nkc * N, 0, h * nkz + c * nkc, G, blk, psum, ns)
+            if last:
+                K.fft_x_bin(recv[nkc * N * nx:], N, nky, h * nky, N // 2, G, blk, psum, ns)
+    tab = pipe.finish(psum, ns)
+    assert np.array_equal(tab[:, 3], ref[:, 3])
+    assert np.allclose(tab[:, 2], ref[:, 2], rtol=1e-6, atol=0)
+
+
+def test_fused_z_images_equal_the_fused_zy_path(K):
+    """vps_deposit_fft_z (+ vps_fft_y with one rank, one chunk) writes what vps_deposit_fft_zy writes (two separate
+    LDS accumulations: the float32 sums may differ in the order of their additions, nothing else)."""
+    from vpower import device
+    N, Np, L = 256, 300_000, 1.0
+    pos, vel, mass, dens = synth(5, Np, L)
+    d = [K.to_device(a) for a in (pos, vel, dens)]
+    for q in (device.VELOCITY, device.ENERGY):
+        spec, nyq = K.deposit_fft_zy(d[0], d[1], d[2], N, L, 64, 32, q)
+        z = K.deposit_fft_z(d[0], d[1], d[2], N, L, 64, 32, q)
+        for c in range(z.shape[0]):
+            out = K.fft_y_chunk(z[c], N, 32, 1, 1, 0)
+            tol = 1e-5 * float(spec[c].abs().square().mean().sqrt().item())
+            assert float((out[: spec[c].numel()] - spec[c].reshape(-1)).abs().max().item()) < tol
+            assert float((out[spec[c].numel():] - nyq[c].reshape(-1)).abs().max().item()) < tol
+    _free(K)

@@ -71,6 +71,7 @@ def _rccl_worker(rank, port, N, Np, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["VPS_FORCE_COLLECTIVES"] = "1"
+    os.environ["VPS_A2A_CHUNKS"] = "4"
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -81,8 +82,9 @@ def _rccl_worker(rank, port, N, Np, out_dir):
         assert comm.backend == "nccl" and comm.force
         pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=comm)
         d = [K.to_device(a) for a in (pos, vel, dens)]
-        spec, nyq = K.deposit_fft_zy(d[0], d[1], d[2], N, 1.0, 0, N, device.VELOCITY)
-        tab = pipe.finish(*pipe.accumulate_spectra(spec, nyq))     # fused path: complex all-to-alls + all-reduces over RCCL
+        assert pipe.chunked and pipe.nchunks == 4
+        z = K.deposit_fft_z(d[0], d[1], d[2], N, 1.0, 0, N, device.VELOCITY)
+        tab = pipe.finish(*pipe.accumulate_zimages([z[0], z[1], z[2]]))   # fused path: chunked complex all-to-alls + all-reduces over RCCL
         fields = K.deposit_field(d[0], d[1], d[2], N, 1.0, 0, N, device.VELOCITY)
         tab2 = pipe.finish(*pipe.accumulate([fields[0], fields[1], fields[2]]))
         np.save(os.path.join(out_dir, "tab_rccl.npy"), np.stack([tab, tab2]))
