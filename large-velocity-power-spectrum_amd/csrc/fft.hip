@@ -423,12 +423,13 @@ __device__ __forceinline__ void exchange_sync() {
 }
 
 // Runs stages 1.. (stage 0 inputs already in v).  On return v holds the spectrum:
-// v[m*RLAST + r] = F[l + L*m + r*NC/RLAST].
-template <int NC, bool WAVE = false>
-__device__ __forceinline__ void fft_from_regs(cf (&v)[PlanInfo<NC>::RL], cf* line, const cf* tw,
-                                              int l) {
+// v[m*RLAST + r] = F[l + L*m + r*NC/RLAST].  L lanes per line (default: the plan's; the persistent transposing pass
+// of the longest lines runs a line on half as many lanes with twice the points each).
+template <int NC, int L, bool WAVE>
+__device__ __forceinline__ void fft_from_regs_l(cf (&v)[NC / L], cf* line, const cf* tw, int l) {
   typedef PlanInfo<NC> PI;
-  constexpr int L = PI::L, RL = PI::RL;
+  constexpr int RL = NC / L;
+  static_assert(RL % PI::R0 == 0 && RL % PI::R1 == 0 && RL % PI::R2 == 0, "radix must divide RL");
   twiddle_butterfly<NC, L, RL, PI::R0, 1>(v, tw, l);
   if constexpr (PI::R1 > 1) {
     lds_store_stage<NC, L, RL, PI::R0, 1>(v, line, l);
@@ -444,6 +445,10 @@ __device__ __forceinline__ void fft_from_regs(cf (&v)[PlanInfo<NC>::RL], cf* lin
     }
   }
 }
+template <int NC, bool WAVE = false>
+__device__ __forceinline__ void fft_from_regs(cf (&v)[PlanInfo<NC>::RL], cf* line, const cf* tw, int l) {
+  fft_from_regs_l<NC, PlanInfo<NC>::L, WAVE>(v, line, tw, l);
+}
 
 template <int NC>
 struct LastRadix {
@@ -452,12 +457,15 @@ struct LastRadix {
 };
 
 // output index of register slot i = m*R + r after the last stage
-template <int NC>
-__device__ __forceinline__ int out_index(int l, int i) {
+template <int NC, int L>
+__device__ __forceinline__ int out_index_l(int l, int i) {
   constexpr int R = LastRadix<NC>::R;
-  constexpr int L = PlanInfo<NC>::L;
   const int m = i / R, r = i % R;
   return l + L * m + r * (NC / R);
+}
+template <int NC>
+__device__ __forceinline__ int out_index(int l, int i) {
+  return out_index_l<NC, PlanInfo<NC>::L>(l, i);
 }
 
 struct PassParams {
@@ -645,6 +653,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
     r2c_store_tile<NC, T, NT, true>(buf, tid, p.tw_r2c, out, p.out_ok, nyq, p.A - a0);
   }
 }
+
 
 // ------------------------------------------------------------------------------
 // Fused deposit + field algebra + z pass ("pencil" kernel).  A pencil is the TP z-lines
@@ -880,9 +889,6 @@ int launch_pencil(vps_ctx* ctx, const PencilParams& p, long long npencils) {
 // binned straight from registers (MODE 0) or written in place order (MODE 1).
 // Persistent workgroups loop over tiles of T lines.
 // ------------------------------------------------------------------------------
-#ifndef VPS_XPIPE_MIN_NC
-#define VPS_XPIPE_MIN_NC 2048
-#endif
 struct XParams {
   const cf* in;            // component 0
   const cf* in1;           // components 1, 2 of a vector field (binning modes, ncomp > 1)
@@ -914,7 +920,6 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   typedef PlanInfo<NC> PI;
   constexpr int L = PI::L, RL = PI::RL, NT = T * L;
   constexpr int H = RL / 2;   // |kx| values per lane on the FAST path
-  constexpr bool PIPE = (MODE == 0) && (NC >= VPS_XPIPE_MIN_NC);   // request the next line before transforming this one
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // carve: thr (double, nbins+2 with a +inf sentinel) | hsum (double) | tw | line buffers | hcnt
   double* thr = reinterpret_cast<double*>(smem_raw);
@@ -1064,40 +1069,20 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
         int lc = l;
         asm volatile("" : "+v"(lc));
         lc = (L & (L - 1)) == 0 ? (lc & (L - 1)) : lc % L;   // give the value range back to the compiler (address folding needs it)
-        if constexpr (PIPE) {
-          // Longest lines: LDS allows two waves per SIMD, so registers are plentiful -- the NEXT transform's inputs (next
-          // component of this tile, or the first of the next tile) are requested before this one starts and arrive
-          // while it runs, instead of being waited for right after being issued.
-          cf w[RL];
-          if (c + 1 < p.ncomp) {
-            load_line(w, c + 1, lc);
-          } else if (tile + gridDim.x < ntiles) {
-            locate_line(tile + gridDim.x);
-            load_line(w, 0, lc);
-          }
-          exchange_sync<WSYNC>();  // previous readers are done with the line buffers
-          fft_from_regs<NC, WSYNC>(v, line, tw, lc);
+        exchange_sync<WSYNC>();  // previous readers are done with the line buffers
+        fft_from_regs<NC, WSYNC>(v, line, tw, lc);
 #pragma unroll
-          for (int i = 0; i < RL; ++i) {
-            const float a = v[i].x * v[i].x + v[i].y * v[i].y;
-            pacc[i] = (c == 0) ? a : pacc[i] + a;
-          }
-#pragma unroll
-          for (int i = 0; i < RL; ++i) v[i] = w[i];
-        } else {
-          exchange_sync<WSYNC>();  // previous readers are done with the line buffers
-          fft_from_regs<NC, WSYNC>(v, line, tw, lc);
-#pragma unroll
-          for (int i = 0; i < RL; ++i) {
-            const float a = v[i].x * v[i].x + v[i].y * v[i].y;
-            pacc[i] = (c == 0) ? a : pacc[i] + a;
-          }
-          if (c + 1 < p.ncomp) {
-            load_line(v, c + 1, lc);
-          } else if (tile + gridDim.x < ntiles) {
-            locate_line(tile + gridDim.x);
-            load_line(v, 0, lc);
-          }
+        for (int i = 0; i < RL; ++i) {
+          const float a = v[i].x * v[i].x + v[i].y * v[i].y;
+          pacc[i] = (c == 0) ? a : pacc[i] + a;
+        }
+        // (Requesting the next line BEFORE this transform -- a second register set, affordable at 2048 where LDS limits
+        // the kernel to two waves per SIMD -- was measured at 2048^3: 73.2 against 72.5 ms per step.  Not kept.)
+        if (c + 1 < p.ncomp) {
+          load_line(v, c + 1, lc);
+        } else if (tile + gridDim.x < ntiles) {
+          locate_line(tile + gridDim.x);
+          load_line(v, 0, lc);
         }
       }
       float* pw = reinterpret_cast<float*>(line);
@@ -1283,6 +1268,10 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
   // CU) measured 13 % faster than 8-line tiles; for the packed-real 1024-point z pass the
   // 8-line tiles with XCD-paired placement are faster.
   // (4-line tiles with four-way XCD grouping were slower at 2048: 2.59 vs 2.25 ms.)
+  // (Persistent workgroups that request the next tile's lines before transforming the current one -- to overlap load,
+  // transform and store where only ONE workgroup fits a CU -- measured at 2048^3: at the plan's 1024 threads the 32
+  // prefetch registers spill (128-VGPR cap); on half the lanes per line (512 threads, 256 VGPRs, wave-level exchanges)
+  // still 124 bytes per lane of scratch and 164 ms per step of y passes against 113 ms for this kernel.  Not kept.)
   constexpr int T = (NC == 1024 && !REAL) ? 16 : transpose_T<NC>();
   typedef PlanInfo<NC> PI;
   const size_t lds = transpose_lds_bytes<NC, T>();
