@@ -143,6 +143,13 @@ int vps_deposit_fft_zy(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const 
                        const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx,
                        int quantity, int flags, void* spec_dev, void* nyq_dev, void* work_dev);
 
+/* Higher-order assignment by expansion (extension): every particle becomes S = order^3 weighted
+ * sub-particles at the centres of the cells it touches (order 2: cloud-in-cell, 3: triangular-shaped cloud; periodic):
+ * pos_out_dev [np*S][3] float32, payload_out_dev [np*S][C] = payload * weight (C <= 4).  Depositing them with
+ * vps_deposit_ngp gives the CIC / TSC grid; with replicated particles every slab gets its contributions without a halo. */
+int vps_assign_expand(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* payload_dev, int64_t np,
+                      int C, int N, double Lbox, int order, float* pos_out_dev, float* payload_out_dev);
+
 /* out_dev[np][4] = [vx*rho, vy*rho, vz*rho, rho]: GasParticles.density_velocity_vector
  * (vpower/interp.py:199-213).  vel_dev [np][3], rho_dev [np], float32.             */
 int vps_density_velocity_vector(vps_ctx* ctx, const float* vel_dev, const float* rho_dev,
@@ -198,6 +205,12 @@ int vps_fft_supported(int N);
  *   edge0, inv_spacing: a first guess b=(sqrt(s)-edge0)*inv_spacing, corrected with thr. */
 int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host,
                     const double* thr_host, int nbins, double edge0, double inv_spacing);
+
+/* Deconvolution of a mass-assignment window in the binning x pass (extension; the reference has no
+ * higher-order assignment): inv_w2_axis_host[N] (float32, indexed like k2_axis, even in k) holds 1 / W(k)^2 of ONE axis,
+ * W(k) = sinc(pi k / (2 k_Nyquist))^p with p = 1 (NGP), 2 (CIC), 3 (TSC); every |F(k)|^2 that vps_fft_x (modes 0, 3) and
+ * vps_fft_x_bin accumulate is multiplied by the product of the three axis factors.  NULL switches it off (default). */
+int vps_set_window(vps_ctx* ctx, int N, const float* inv_w2_axis_host);
 
 /* Local part of the transform on an x-slab: z pass (R2C) and y pass.
  * field_dev: [nx][N][N] float32 real input (NOT modified).

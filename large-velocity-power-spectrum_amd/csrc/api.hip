@@ -84,6 +84,7 @@ int vps_destroy(vps_ctx* ctx) {
   if (ctx->d_thr) (void)hipFree(ctx->d_thr);
   if (ctx->d_axes) (void)hipFree(ctx->d_axes);
   if (ctx->d_xpart) (void)hipFree(ctx->d_xpart);
+  if (ctx->d_win) (void)hipFree(ctx->d_win);
   for (auto& l : ctx->launches) {
     (void)hipEventDestroy(l.start);
     (void)hipEventDestroy(l.stop);
@@ -250,6 +251,33 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
   ctx->nbins = nbins;
   ctx->edge0 = edge0;
   ctx->inv_spacing = inv_spacing;
+  return VPS_OK;
+}
+
+int vps_set_window(vps_ctx* ctx, int N, const float* inv_w2_axis_host) {
+  VPS_ENTER(ctx);
+  if (!inv_w2_axis_host) {                       // back to no deconvolution
+    if (ctx->d_win) {
+      VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      VPS_HIP_CHECK(ctx, hipFree(ctx->d_win));
+    }
+    ctx->d_win = nullptr;
+    ctx->win_N = 0;
+    ctx->h_win.clear();
+    return VPS_OK;
+  }
+  if (N < 2) return vps_fail(ctx, VPS_ERR_ARG, "vps_set_window: N=%d", N);
+  for (int i = 1; i < N / 2; ++i)
+    if (inv_w2_axis_host[i] != inv_w2_axis_host[N - i])
+      return vps_fail(ctx, VPS_ERR_ARG, "vps_set_window: the table must be even in k (entry %d != entry %d)", i, N - i);
+  if (ctx->d_win && ctx->win_N == N && memcmp(ctx->h_win.data(), inv_w2_axis_host, sizeof(float) * N) == 0) return VPS_OK;
+  VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->d_win) VPS_HIP_CHECK(ctx, hipFree(ctx->d_win));
+  ctx->d_win = nullptr;
+  VPS_HIP_CHECK(ctx, hipMalloc(&ctx->d_win, sizeof(float) * N));
+  VPS_HIP_CHECK(ctx, hipMemcpy(ctx->d_win, inv_w2_axis_host, sizeof(float) * N, hipMemcpyHostToDevice));
+  ctx->h_win.assign(inv_w2_axis_host, inv_w2_axis_host + N);
+  ctx->win_N = N;
   return VPS_OK;
 }
 

@@ -667,6 +667,53 @@ __global__ void __launch_bounds__(256)
       make_float4(vel[i * 3 + 0] * r, vel[i * 3 + 1] * r, vel[i * 3 + 2] * r, r);
 }
 
+// Higher-order mass assignment (cloud-in-cell: 2 cells per axis, triangular-shaped-cloud: 3): every particle becomes
+// S = 8 or 27 weighted sub-particles sitting at the centres of the cells it touches (periodic), which the NGP
+// deposit then adds up -- no new deposit kernel, and with replicated particles no halo exchange between slabs.
+// Not in the reference (it offers NGP interp.py:996, NN :1018 and Voxelize :280); SURVEY.md section 8(f-4).
+template <typename F>
+__global__ void __launch_bounds__(256)
+    assign_expand_kernel(const F* __restrict__ pos, const float* __restrict__ payload, long long np, int C, int N,
+                         double inv_lcell, double lcell, int order, float* __restrict__ pos_out,
+                         float* __restrict__ payload_out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  int c0[3];
+  float w[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double s = (double)pos[i * 3 + a] * inv_lcell;
+    if (order == 2) {            // CIC: cells floor(s - 1/2) and the next one, weights 1 - f, f
+      const double f0 = floor(s - 0.5);
+      const float f = (float)(s - 0.5 - f0);
+      c0[a] = (int)f0;
+      w[a][0] = 1.f - f;
+      w[a][1] = f;
+      w[a][2] = 0.f;
+    } else {                     // TSC: the cell holding the particle and its two neighbours
+      const double ic = floor(s);
+      const float d = (float)(s - (ic + 0.5));
+      c0[a] = (int)ic - 1;
+      w[a][0] = 0.5f * (0.5f - d) * (0.5f - d);
+      w[a][1] = 0.75f - d * d;
+      w[a][2] = 0.5f * (0.5f + d) * (0.5f + d);
+    }
+  }
+  const int S1 = order, S = S1 * S1 * S1;
+  float pay[4];
+  for (int c = 0; c < C; ++c) pay[c] = payload[i * C + c];
+  for (int j = 0; j < S; ++j) {
+    const int jx = j / (S1 * S1), jy = (j / S1) % S1, jz = j % S1;
+    const float wt = w[0][jx] * w[1][jy] * w[2][jz];
+    const int cx = ((c0[0] + jx) % N + N) % N, cy = ((c0[1] + jy) % N + N) % N, cz = ((c0[2] + jz) % N + N) % N;
+    float* po = pos_out + (i * S + j) * 3;
+    po[0] = (float)(((double)cx + 0.5) * lcell);
+    po[1] = (float)(((double)cy + 0.5) * lcell);
+    po[2] = (float)(((double)cz + 0.5) * lcell);
+    for (int c = 0; c < C; ++c) payload_out[(i * S + j) * C + c] = pay[c] * wt;
+  }
+}
+
 // LDS tile of one brick: 32 KiB -> four bricks resident per CU, enough workgroups in
 // flight to hide the bucket-read -> LDS-add -> stream-out dependency chain of each one
 #define VPS_BRICK_LDS_BYTES (32 * 1024)
@@ -1043,6 +1090,31 @@ int vps_density_velocity_vector(vps_ctx* ctx, const float* vel_dev, const float*
     vps_launch_timer tm(ctx, VPS_K_MISC);
     hipLaunchKernelGGL(rhov_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, vel_dev,
                        rho_dev, (long long)np, out_dev);
+  }
+  VPS_HIP_CHECK(ctx, hipGetLastError());
+  return VPS_OK;
+}
+
+int vps_assign_expand(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* payload_dev, int64_t np,
+                      int C, int N, double Lbox, int order, float* pos_out_dev, float* payload_out_dev) {
+  VPS_ENTER(ctx);
+  if (np < 0 || N < 1 || !(Lbox > 0) || C < 1 || C > 4) return vps_fail(ctx, VPS_ERR_ARG, "vps_assign_expand: bad np/N/Lbox/C");
+  if (order != 2 && order != 3) return vps_fail(ctx, VPS_ERR_ARG, "vps_assign_expand: order must be 2 (CIC) or 3 (TSC)");
+  if (np == 0) return VPS_OK;
+  if (!pos_dev || !payload_dev || !pos_out_dev || !payload_out_dev) return vps_fail(ctx, VPS_ERR_ARG, "vps_assign_expand: null buffer");
+  if ((np + 255) / 256 > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "np too large for one launch");
+  const double lcell = Lbox / (double)N;
+  {
+    vps_launch_timer tm(ctx, VPS_K_DEPOSIT);
+    const unsigned blocks = (unsigned)((np + 255) / 256);
+    if (pos_is_f64)
+      hipLaunchKernelGGL(assign_expand_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream,
+                         reinterpret_cast<const double*>(pos_dev), payload_dev, (long long)np, C, N, 1.0 / lcell, lcell,
+                         order, pos_out_dev, payload_out_dev);
+    else
+      hipLaunchKernelGGL(assign_expand_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream,
+                         reinterpret_cast<const float*>(pos_dev), payload_dev, (long long)np, C, N, 1.0 / lcell, lcell,
+                         order, pos_out_dev, payload_out_dev);
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
   return VPS_OK;

@@ -902,6 +902,7 @@ struct XParams {
   const cf* tw_stage;
   const double* k2;
   const double* thr;
+  const float* win;        // 1 / W^2 per axis index (vps_set_window) or NULL
   int nbins;
   float edge0, inv_spacing;
   double* psum;
@@ -928,6 +929,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   cf* buf = tw_lds + PI::TWL;
   const cf* tw = PI::TWLDS ? tw_lds : p.tw_stage;
   unsigned* hcnt = reinterpret_cast<unsigned*>(buf + T * PI::PITCH);
+  float* wl = reinterpret_cast<float*>(hcnt + ((MODE == 0 && COUNT) ? p.nbins : 0));   // [NC] window factors (MODE 0 with p.win)
 
   const int tid = threadIdx.x;
   const int t = tid / L, l = tid % L;
@@ -943,6 +945,8 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
       hsum[i] = 0.0;
       if constexpr (COUNT) hcnt[i] = 0u;
     }
+    if (p.win)
+      for (int i = tid; i < NC; i += NT) wl[i] = p.win[i];
     if constexpr (FAST) {
 #pragma unroll
       for (int i = 0; i < H; ++i) k2x[i] = p.k2[l * H + i];
@@ -968,6 +972,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   long long li = 0;
   bool live = false, mirrored = false, has_partner = false;
   double k2y = 0.0, k2z = 0.0;   // fl(ky*ky), fl(kz*kz) of the line (MODE 0)
+  float wyz = 1.f;               // window factor of the line's (ky, kz)
   unsigned wz = 1u;              // Hermitian multiplicity of its kz plane
   double k2half = 0.0;
   if constexpr (MODE == 0) k2half = p.k2[NC / 2];
@@ -994,6 +999,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
         k2y = p.k2[(int)(g % p.N)];
         k2z = p.k2[kz];
         wz = (kz == 0 || 2 * kz == p.N) ? 1u : 2u;
+        if (p.win) wyz = p.win[(int)(g % p.N)] * p.win[kz];
       }
     }
   };
@@ -1032,6 +1038,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
     const bool live_cur = live, mirrored_cur = mirrored, partner_cur = has_partner;
     const double k2y_cur = k2y, k2z_cur = k2z;
     const unsigned wz_cur = wz;
+    const float wyz_cur = wyz;
     if constexpr (MODE != 0) {
       exchange_sync<WSYNC>();  // previous tile's readers are done with the line buffers
       fft_from_regs<NC, WSYNC>(v, line, tw, l);
@@ -1102,7 +1109,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
       if constexpr (FAST) {
         if (live_cur && !mirrored_cur) {
           const unsigned w = wz_cur * (partner_cur ? 2u : 1u);
-          const float wf = (float)wz_cur;
+          const float wf = (float)wz_cur * wyz_cur;   // Hermitian multiplicity x window factor of (ky, kz)
           // the partner line's |F|^2 image is the next line buffer
           constexpr int POFF = PI::PITCH * 2;
           const float* mine = pw + l * (H + 1);                        // kx = l*H + i
@@ -1130,6 +1137,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
               c = 2u;
             }
             if ((unsigned)bin < (unsigned)p.nbins) {
+              if (p.win) pv *= wl[l * H + i];
               atomicAdd(&hsum[bin], (double)(pv * wf));
               if constexpr (COUNT) atomicAdd(&hcnt[bin], c * w);
             }
@@ -1144,6 +1152,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
             if ((unsigned)bin < (unsigned)p.nbins) {
               float pv = pw[NC / 2 + L];
               if (partner_cur) pv += pw[NC / 2 + L + POFF];
+              if (p.win) pv *= wl[NC / 2];
               atomicAdd(&hsum[bin], (double)(pv * wf));
               if constexpr (COUNT) atomicAdd(&hcnt[bin], w);
             }
@@ -1152,7 +1161,8 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
       } else if (live_cur) {
         const double k2y = k2y_cur, k2z = k2z_cur;
         const unsigned w = wz_cur;
-        const double wd = (double)w;
+        const double wd = (double)w * (double)wyz_cur;
+        const int kx0 = l * RL + (rev ? RL - 1 : 0);     // kx index of the chunk's first element in walking order
         // walk the chunk in the direction of non-decreasing |kx| (k2x was loaded that way)
         const float* mine = pw + l * (RL + 1) + (rev ? RL - 1 : 0);
         const int step = rev ? -1 : 1;
@@ -1192,7 +1202,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
             hi = lo;
             lo = (cur >= 0) ? thr[cur] : -INFINITY;
           }
-          acc += (double)mine[i * step];
+          acc += (double)(p.win ? mine[i * step] * wl[kx0 + i * step] : mine[i * step]);
           ++cnt;
         }
         flush();
@@ -1300,7 +1310,8 @@ int launch_x(vps_ctx* ctx, const XParams& p_in, bool fast = false) {
   constexpr int T = xpass_T<NC>();
   typedef PlanInfo<NC> PI;
   size_t lds = (PI::TWL + (size_t)T * PI::PITCH) * sizeof(cf);
-  if (MODE == 0) lds += (size_t)(2 * p.nbins + 2) * sizeof(double) + (COUNT ? (size_t)p.nbins * sizeof(unsigned) : 0);
+  if (MODE == 0) lds += (size_t)(2 * p.nbins + 2) * sizeof(double) + (COUNT ? (size_t)p.nbins * sizeof(unsigned) : 0) +
+                        (p.win ? (size_t)NC * sizeof(float) : 0);
   if (lds > ctx->lds_per_cu) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "x pass needs %zu B LDS", lds);
   const bool seg = p.seglen != NC;
   auto kern = seg ? fft_x_pass<NC, T, MODE, true, COUNT, false> : fft_x_pass<NC, T, MODE, false, COUNT, false>;
@@ -1814,6 +1825,8 @@ static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz
     if (kz0 + (int)(maxline / N) > N / 2) return vps_fail(ctx, VPS_ERR_ARG, "kz range exceeds N/2");
     p.k2 = ctx->d_k2;
     p.thr = ctx->d_thr;
+    if (ctx->d_win && ctx->win_N != N) return vps_fail(ctx, VPS_ERR_ARG, "vps_set_window was called for N=%d, not %d", ctx->win_N, N);
+    p.win = ctx->d_win;
     p.nbins = ctx->nbins;
     p.edge0 = (float)ctx->edge0;
     p.inv_spacing = (float)ctx->inv_spacing;

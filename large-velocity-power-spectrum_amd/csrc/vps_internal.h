@@ -38,6 +38,11 @@ struct vps_ctx {
   bool bin_fast = false;    // k2 table symmetric and monotone: mirrored-kx binning is valid
   std::vector<double> h_k2, h_thr;  // host copies, to skip re-uploading identical tables
 
+  // 1 / W(k)^2 per axis index of the mass-assignment window (vps_set_window); NULL: no deconvolution
+  float* d_win = nullptr;
+  int win_N = 0;
+  std::vector<float> h_win;
+
   // per-workgroup partial shell sums of the x pass
   void* d_xpart = nullptr;
   size_t xpart_cap = 0;

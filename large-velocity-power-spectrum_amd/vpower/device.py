@@ -62,6 +62,20 @@ def bin_edges(kmin, kmax, spacing, flavour="library"):
     return centers, edges
 
 
+ASSIGNMENT_ORDER = {"ngp": 1, "cic": 2, "tsc": 3}
+
+
+def window_inv2_axis(Nsize, assignment):
+    """1 / W(k)^2 of one axis for the mass-assignment window W(k) = sinc(pi k / (2 k_Nyquist))^p, p = 1 (NGP),
+    2 (CIC), 3 (TSC), indexed like fftfreq (float32).  The three axis factors multiply."""
+    p = ASSIGNMENT_ORDER[assignment]
+    n = np.fft.fftfreq(Nsize, 1.0 / Nsize)          # integer mode numbers
+    x = np.pi * n / Nsize
+    with np.errstate(invalid="ignore", divide="ignore"):
+        w = np.where(n == 0, 1.0, np.sin(x) / x)
+    return (w ** (-2.0 * p)).astype(np.float32)
+
+
 def sqrt_thresholds(edges):
     """thr[i] = smallest float64 t with sqrt(t) >= edges[i] (i < nbins) and
     thr[nbins] = smallest t with sqrt(t) > edges[nbins], so that comparing
@@ -352,6 +366,32 @@ class HipKernels:
         self._chk(self.lib.vps_set_binning(self.ctx, N, _ffi.as_dp(k2), _ffi.as_dp(thr), len(thr) - 1,
                                            float(edge0), float(inv_spacing)))
 
+    def set_window(self, N, table):
+        """1/W^2 axis table (window_inv2_axis) for the binning x pass, or None to switch deconvolution off."""
+        self._stream()
+        if table is None:
+            self._chk(self.lib.vps_set_window(self.ctx, int(N), None))
+            return
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        if t.shape != (N,):
+            raise _ffi.VpsError("window table must have N entries")
+        self._chk(self.lib.vps_set_window(self.ctx, int(N), t.ctypes.data_as(C.c_void_p)))
+
+    def assign_expand(self, pos, payload, N, Lbox, assignment):
+        """CIC / TSC: (pos [np,3], payload [np,C]) -> weighted sub-particles at cell centres
+        (pos' float32 [np*S,3], payload' [np*S,C]); deposit them with `deposit`."""
+        self._stream()
+        order = ASSIGNMENT_ORDER[assignment]
+        if order == 1:
+            return pos, payload
+        S = order ** 3
+        n, C_ = payload.shape
+        pos_o = self.empty((n * S, 3), torch.float32)
+        pay_o = self.empty((n * S, C_), torch.float32)
+        self._chk(self.lib.vps_assign_expand(self.ctx, self._ptr(pos), self._pos_kind(pos), self._ptr(payload, torch.float32),
+                                             n, C_, int(N), float(Lbox), order, self._ptr(pos_o), self._ptr(pay_o)))
+        return pos_o, pay_o
+
     def fft_zy(self, field, N, nx, spec=None, nyq=None, weight=None):
         """field [nx,N,N] float32 (times `weight`, same shape, if given) -> spec [N/2,N,nx], nyq [N,nx] (complex64)."""
         self._stream()
@@ -568,7 +608,7 @@ class PowerPipeline:
     ranks of `comm` (default: the initialised torch.distributed world, else 1 rank)."""
 
     def __init__(self, Nsize, Lbox, kernels=None, comm=None, flavour="library",
-                 kmin=None, kmax=None, kres=None):
+                 kmin=None, kmax=None, kres=None, deconvolve=None):
         self.N = int(Nsize)
         self.Lbox = float(Lbox)
         self.Lcell = self.Lbox / self.N
@@ -594,6 +634,8 @@ class PowerPipeline:
         spacing = (self.edges[-1] - self.edges[0]) / self.nbins
         self._binning = (self.N, self.k2, self.thr, float(self.edges[0]), 1.0 / spacing)
         self.const = (self.Lbox / (2 * np.pi)) ** 1.5 / self.N ** 3   # interp.py:1381
+        # deconvolve = "ngp" | "cic" | "tsc": divide every |F(k)|^2 by the assignment window W(k)^2 while binning
+        self.window = None if deconvolve is None else window_inv2_axis(self.N, deconvolve)
         # Several ranks: every scalar field crosses the node as ONE message per pair of ranks (its kz rows with the
         # Nyquist-plane rows riding behind them), cut into `nchunks` kz chunks so that the exchange of a chunk
         # overlaps the y pass of the next and the x pass of the previous one.
@@ -622,6 +664,7 @@ class PowerPipeline:
         N, nx, G, r = self.N, self.nx, self.comm.world, self.comm.rank
         k = self.k
         k.set_binning(*self._binning)
+        self._set_window()
         if psum is None:
             psum, nsample = self.new_accumulators()
         C_ = self.nchunks
@@ -654,6 +697,7 @@ class PowerPipeline:
         N, nx, G, r = self.N, self.nx, self.comm.world, self.comm.rank
         k = self.k
         k.set_binning(*self._binning)
+        self._set_window()
         if psum is None:
             psum, nsample = self.new_accumulators()
         if self.chunked:
@@ -694,6 +738,7 @@ class PowerPipeline:
                             "and PowerPipeline.accumulate_zimages")
         k = self.k
         k.set_binning(*self._binning)
+        self._set_window()
         if psum is None:
             psum, nsample = self.new_accumulators()
         nkz, nky = N // 2 // G, N // G
@@ -701,6 +746,12 @@ class PowerPipeline:
                    for i in range(spec.shape[0])]
         self._bin_exchanged(pending, psum, nsample, count)
         return psum, nsample
+
+    def _set_window(self):
+        if hasattr(self.k, "set_window"):
+            self.k.set_window(self.N, self.window)
+        elif self.window is not None:
+            raise Exception("this kernel set has no window deconvolution")
 
     def new_accumulators(self):
         """Zeroed shell sums (float64) and shell counts (int64) as two views of ONE device buffer, so that a

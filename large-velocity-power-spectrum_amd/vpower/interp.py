@@ -136,13 +136,26 @@ class GasParticles:
         k.field_algebra(grid, _dev.VM, 0, Lcell)
         return BoxField._from_device(grid, Lcell)
 
-    def deposit_to_field(self, Nsize):
+    def deposit_to_field(self, Nsize, assignment="ngp"):
         """NGP composition the reference leaves to the caller: deposit_to_grid of
         density_velocity_vector (interp.py:996-1015), then v=rho v/rho with empty cells set
-        to 0 (the rule of interp.py:329-331) and m=rho*Lcell^3 (interp.py:272-273)."""
+        to 0 (the rule of interp.py:329-331) and m=rho*Lcell^3 (interp.py:272-273).
+        `assignment` = "cic" / "tsc" (extension; the reference offers NGP, NN and Voxelize) spreads
+        [rho v, rho] over 8 / 27 cells; `BoxField.spctrm(..., deconvolve=True)` then divides the
+        spectrum by the assignment window."""
         k = _kernels()
         vel = k.to_device(np.asarray(self.v), torch.float32)
         rho = k.to_device(np.asarray(self.density), torch.float32)
+        if assignment != "ngp":
+            if assignment not in _dev.ASSIGNMENT_ORDER:
+                raise Exception("assignment must be 'ngp', 'cic' or 'tsc'")
+            pos_e, pay_e = k.assign_expand(_pos_tensor(k, self.pos), k.density_velocity_vector(vel, rho), Nsize, self.Lbox,
+                                           assignment)
+            grid = k.deposit(pos_e, pay_e, Nsize, self.Lbox, 0, Nsize)
+            k.field_algebra(grid, _dev.VM, 0, self.Lbox / Nsize)
+            box = BoxField._from_device(grid, self.Lbox / Nsize)
+            box.assignment = assignment
+            return box
         # The grid itself is built on first use: `deposit_to_field(N).spctrm(...)`, the usual composition, goes
         # from the particles to P(k) through the fused deposit + z-pass kernel and never writes a grid.
         return BoxField._from_particles((_pos_tensor(k, self.pos), vel, rho), Nsize, self.Lbox)
@@ -277,12 +290,15 @@ class BoxField:
         """P of E = mass*(vx^2+vy^2+vz^2) (interp.py:544-557)."""
         return self._power("energy")
 
-    def spctrm(self, quantity="velocity", kmin=None, kmax=None, kres=None) -> PowerSpectrum:
+    def spctrm(self, quantity="velocity", kmin=None, kmax=None, kres=None, deconvolve=False) -> PowerSpectrum:
         """Binned spectrum, P multiplied by 4 pi k^2 (interp.py:560-595): z/y/x FFT passes
-        with |F|^2 and the shell histogram fused into the last pass."""
+        with |F|^2 and the shell histogram fused into the last pass.  `deconvolve` (extension): divide
+        |F(k)|^2 by the window W(k)^2 of the field's mass assignment (`deposit_to_field(N, assignment=...)`;
+        exact for the linearly assigned momentum density, a customary approximation for v = rho v / rho)."""
         k = _kernels()
         pipe = _dev.PowerPipeline(self.Nsize, self.Lbox, kernels=k, comm=_dev.SlabComm(enabled=False),
-                                  flavour="library", kmin=kmin, kmax=kmax, kres=kres)
+                                  flavour="library", kmin=kmin, kmax=kmax, kres=kres,
+                                  deconvolve=(getattr(self, "assignment", "ngp") if deconvolve else None))
         src = getattr(self, "_src", None)
         if quantity not in _dev.QUANTITY:
             raise Exception("""Unrecognized physical quantity name.
@@ -346,9 +362,10 @@ def check_conservation(gasParticles, boxField) -> tuple:
 # --------------------------------------------------------------------------- #
 # free functions
 # --------------------------------------------------------------------------- #
-def deposit_to_grid(f, pos, Nsize, Lbox):
+def deposit_to_grid(f, pos, Nsize, Lbox, assignment="ngp"):
     """Nearest-grid-point scatter-add of f (Np,) or (Np,C) into an (N,N,N[,C]) float64 grid;
-    cell = int((pos // Lcell) % Nsize), periodic (interp.py:996-1015)."""
+    cell = int((pos // Lcell) % Nsize), periodic (interp.py:996-1015).  `assignment` = "cic" / "tsc"
+    (extension) spreads every particle over 8 / 27 cells."""
     k = _kernels()
     f = np.asarray(f)
     f2 = f[:, None] if f.ndim == 1 else f
@@ -359,7 +376,8 @@ def deposit_to_grid(f, pos, Nsize, Lbox):
     c = 0
     while c < f2.shape[1]:      # the kernel takes 1, 3 or 4 channels per launch
         w = 4 if f2.shape[1] - c >= 4 else (3 if f2.shape[1] - c == 3 else 1)
-        g = k.deposit(post, k.to_device(f2[:, c:c + w], torch.float32), Nsize, Lbox, 0, Nsize)
+        pe, fe = k.assign_expand(post, k.to_device(f2[:, c:c + w], torch.float32), Nsize, Lbox, assignment)
+        g = k.deposit(pe, fe, Nsize, Lbox, 0, Nsize)
         cols.append(g)
         c += w
     grid = torch.cat(cols, dim=0).permute(1, 2, 3, 0).cpu().numpy().astype(np.float64)
