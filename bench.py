@@ -176,7 +176,7 @@ class Workload:
         if self.route == "ngp":
             return "fused deposit+z pass (pencil buckets)" if self.fused else "deposit -> grid -> z pass"
         if self.route == "nn":
-            return "exact-NN resample (library lattice) -> [rho v, rho] grid -> v, m -> z pass (p = v*m formed in the pass)"
+            return "exact-NN resample (library lattice) with v, m formed in its epilogue -> z pass (p = v*m formed in the pass)"
         return "exact-NN resample (script lattice, raw velocities) -> grid -> z pass"
 
     def _table(self):
@@ -211,8 +211,7 @@ class Workload:
             return out
         if self.route == "nn":
             payload = K.density_velocity_vector(self.vel, self.rho)              # interp.py:199-213
-            g, _ = K.nn_resample(self.pos, payload, self.axes, x0, nx, out=self.grid)
-            K.field_algebra(g, dev.VM, 0, L / N)                                  # interp.py:272-273
+            g, _ = K.nn_resample_field(self.pos, payload, self.axes, x0, nx, L / N, out=self.grid)   # + interp.py:272-273
             for q in self.quantities:
                 self.acc_buf.zero_()
                 if q == "momentum":

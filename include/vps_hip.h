@@ -175,6 +175,14 @@ int vps_nn_resample(vps_ctx* ctx, const void* pos_dev, int pos_is_f64,
                     const double* qz_host, int nqz, int x0, int nx,
                     float* out_dev, int32_t* nn_idx_dev, void* work_dev);
 
+/* The same search with the algebra of GasParticles.ann_interp_to_field (vpower/interp.py:272-273) in its epilogue:
+ * rhov_dev [np][4] = density_velocity_vector; out_dev [4][nx][nqy][nqz] = vx, vy, vz (= rho v / rho of the nearest
+ * particle) and mass (= rho * Lcell^3): the BoxField form, without a separate pass over the grid. */
+int vps_nn_resample_field(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* rhov_dev,
+                          int64_t np, const double* qx_host, int nqx, const double* qy_host, int nqy,
+                          const double* qz_host, int nqz, int x0, int nx, double Lcell,
+                          float* out_dev, int32_t* nn_idx_dev, void* work_dev);
+
 /* ---- stage A3: field algebra ------------------------------------------- */
 /* chans_dev: [4][ncell] = rho*vx, rho*vy, rho*vz, rho (density_velocity_vector,
  * interp.py:199-213, after deposit/resample).  In place:

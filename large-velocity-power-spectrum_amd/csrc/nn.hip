@@ -127,6 +127,31 @@ constexpr int NN_MAXREC = 1024;    // staged records (16 KiB)
 
 __device__ __forceinline__ float4 srec_load(const float4* __restrict__ srec, unsigned i) { return srec[i]; }
 
+// Output of one lattice point: the payload of its nearest particle, channel-major -- or, with vol > 0 and C = 4
+// ([rho v, rho] payload), the BoxField form v = rho v / rho, mass = rho * Lcell^3 (interp.py:272-273) right away.
+template <int C>
+__device__ __forceinline__ void nn_emit(const float* __restrict__ payload, long long bi, long long q, long long nq,
+                                        float* __restrict__ out, float vol) {
+  if constexpr (C == 4) {
+    const float4 v = *reinterpret_cast<const float4*>(payload + bi * 4);
+    if (vol > 0.f) {
+      const float inv = v.w != 0.f ? 1.f / v.w : 0.f;
+      out[q] = v.x * inv;
+      out[nq + q] = v.y * inv;
+      out[2 * nq + q] = v.z * inv;
+      out[3 * nq + q] = v.w * vol;
+    } else {
+      out[q] = v.x;
+      out[nq + q] = v.y;
+      out[2 * nq + q] = v.z;
+      out[3 * nq + q] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) out[(long long)ch * nq + q] = payload[bi * C + ch];
+  }
+}
+
 struct NnBest {
   double best;
   float screen;
@@ -236,7 +261,7 @@ __global__ void __launch_bounds__(256)
                     const double* __restrict__ qx, const double* __restrict__ qy,
                     const double* __restrict__ qz, int x0, int nx, int nqy, int nqz,
                     const float* __restrict__ payload, float* __restrict__ out,
-                    int* __restrict__ nn_idx) {
+                    int* __restrict__ nn_idx, float vol) {
   __shared__ unsigned lstart[NN_MAXCELL];
   __shared__ float4 lrec[NN_MAXREC];
   __shared__ int range[6];        // min/max of cx, cy, cz over the tile
@@ -376,10 +401,7 @@ __global__ void __launch_bounds__(256)
       const long long nq = (long long)nx * nqy * nqz;
       const long long q = ((long long)ox * nqy + oy) * nqz + oz;
       if (nn_idx) nn_idx[q] = bi;
-      if (out) {
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) out[(long long)ch * nq + q] = payload[(long long)bi * C + ch];
-      }
+      if (out) nn_emit<C>(payload, bi, q, nq, out, vol);
     }
   }
 }
@@ -432,6 +454,7 @@ struct NnScatterParams {
   int ablate;           // timing experiments only: skip the atomics (results are garbage)
   const float* payload;
   float* out;
+  float vol;             // > 0 (C = 4): emit v = rho v / rho, mass = rho * vol instead of the raw payload
   int* nn_idx;
   unsigned* list;        // unresolved lattice points (offsets inside the slab), capacity = all points
   unsigned* list_count;
@@ -679,10 +702,7 @@ __global__ void __launch_bounds__(NT_THREADS) nn_scatter_kernel(const F* __restr
     const bool ok = (bi != 0xffffffffu && screen <= c_init && !contested[i]) || p.ablate;
     if (ok) {
       if (p.nn_idx) p.nn_idx[q] = (int)bi;
-      if (p.out) {
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) p.out[(long long)ch * nqs + q] = p.payload[(long long)bi * C + ch];
-      }
+      if (p.out) nn_emit<C>(p.payload, bi, q, nqs, p.out, p.vol);
     } else {
       p.list[atomicAdd(p.list_count, 1u)] = (unsigned)q;
     }
@@ -696,7 +716,7 @@ __global__ void __launch_bounds__(256)
                        NnGrid g, float err, const double* __restrict__ qx, const double* __restrict__ qy,
                        const double* __restrict__ qz, int x0, int nx, int nqy, int nqz,
                        const unsigned* __restrict__ list, const unsigned* __restrict__ list_count,
-                       const float* __restrict__ payload, float* __restrict__ out, int* __restrict__ nn_idx) {
+                       const float* __restrict__ payload, float* __restrict__ out, int* __restrict__ nn_idx, float vol) {
   const unsigned n = *list_count;
   const long long nqs = (long long)nx * nqy * nqz;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -710,10 +730,7 @@ __global__ void __launch_bounds__(256)
     NnBest b{INFINITY, INFINITY, 0x7fffffff};
     nn_ring_search<F>(pos, srec, start, g, c, Q, Qf, err, 0, b);
     if (nn_idx) nn_idx[q] = b.idx;
-    if (out) {
-#pragma unroll
-      for (int ch = 0; ch < C; ++ch) out[(long long)ch * nqs + q] = payload[(long long)b.idx * C + ch];
-    }
+    if (out) nn_emit<C>(payload, b.idx, q, nqs, out, vol);
   }
 }
 
@@ -775,7 +792,7 @@ struct NnAxesModel {
 template <typename F>
 int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, int x0, int nx,
            int nqy, int nqz, const double* dqx, const double* dqy, const double* dqz, double qmax,
-           const NnAxesModel& model, float* out, int* nn_idx, char* work) {
+           const NnAxesModel& model, float* out, int* nn_idx, char* work, float vol) {
   const long long nq_slab = (long long)nx * nqy * nqz;
   const NnLayout l = nn_layout(np, sizeof(F) == 8, nq_slab);
   NnHeader* hdr = reinterpret_cast<NnHeader*>(work + l.header);
@@ -837,6 +854,7 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
     sp.ablate = getenv("VPS_NN_ABLATE") ? 1 : 0;
     sp.payload = payload;
     sp.out = out;
+    sp.vol = vol;
     sp.nn_idx = nn_idx;
     sp.list = reinterpret_cast<unsigned*>(work + l.list);
     sp.list_count = reinterpret_cast<unsigned*>(work + l.list_count);
@@ -850,7 +868,7 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
     hipLaunchKernelGGL((nn_scatter_kernel<F, CC>), dim3((unsigned)tiles), dim3(NT_THREADS), 0, ctx->stream, pos, sp); \
     hipLaunchKernelGGL((nn_fallback_kernel<F, CC>), dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, ctx->stream, \
                        pos, srec, start, g, err, dqx, dqy, dqz, x0, nx, nqy, nqz, sp.list, sp.list_count, payload, \
-                       out, nn_idx);                                                                           \
+                       out, nn_idx, vol);                                                                      \
   } while (0)
       switch (C) {
         case 1: VPS_NNS(1); break;
@@ -876,7 +894,7 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
     vps_launch_timer tm(ctx, VPS_K_NN_QUERY);
 #define VPS_NNQ(CC)                                                                                  \
   hipLaunchKernelGGL((nn_query_kernel<F, CC>), dim3((unsigned)qblocks), dim3(256), 0, ctx->stream, \
-                     pos, srec, start, g, err, dqx, dqy, dqz, x0, nx, nqy, nqz, payload, out, nn_idx)
+                     pos, srec, start, g, err, dqx, dqy, dqz, x0, nx, nqy, nqz, payload, out, nn_idx, vol)
     switch (C) {
       case 1: VPS_NNQ(1); break;
       case 3: VPS_NNQ(3); break;
@@ -898,11 +916,34 @@ size_t vps_nn_workspace_bytes(int64_t np, int pos_is_f64, int64_t nq_slab) {
   return nn_layout(np, pos_is_f64, nq_slab).total;
 }
 
+static int nn_resample_impl(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* payload_dev,
+                            int64_t np, int C, const double* qx_host, int nqx, const double* qy_host, int nqy,
+                            const double* qz_host, int nqz, int x0, int nx, float* out_dev,
+                            int32_t* nn_idx_dev, void* work_dev, float vol);
+
 int vps_nn_resample(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* payload_dev,
                     int64_t np, int C, const double* qx_host, int nqx, const double* qy_host, int nqy,
                     const double* qz_host, int nqz, int x0, int nx, float* out_dev,
                     int32_t* nn_idx_dev, void* work_dev) {
   VPS_ENTER(ctx);
+  return nn_resample_impl(ctx, pos_dev, pos_is_f64, payload_dev, np, C, qx_host, nqx, qy_host, nqy, qz_host, nqz, x0, nx,
+                          out_dev, nn_idx_dev, work_dev, 0.f);
+}
+
+int vps_nn_resample_field(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* rhov_dev,
+                          int64_t np, const double* qx_host, int nqx, const double* qy_host, int nqy,
+                          const double* qz_host, int nqz, int x0, int nx, double Lcell, float* out_dev,
+                          int32_t* nn_idx_dev, void* work_dev) {
+  VPS_ENTER(ctx);
+  if (!(Lcell > 0) || !out_dev) return vps_fail(ctx, VPS_ERR_ARG, "vps_nn_resample_field: bad Lcell / null output");
+  return nn_resample_impl(ctx, pos_dev, pos_is_f64, rhov_dev, np, 4, qx_host, nqx, qy_host, nqy, qz_host, nqz, x0, nx,
+                          out_dev, nn_idx_dev, work_dev, (float)(Lcell * Lcell * Lcell));
+}
+
+static int nn_resample_impl(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* payload_dev,
+                            int64_t np, int C, const double* qx_host, int nqx, const double* qy_host, int nqy,
+                            const double* qz_host, int nqz, int x0, int nx, float* out_dev,
+                            int32_t* nn_idx_dev, void* work_dev, float vol) {
   if (np < 1) return vps_fail(ctx, VPS_ERR_ARG, "vps_nn_resample: need at least one particle");
   if (np > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_nn_resample: np exceeds int32 indices");
   if (nqx < 1 || nqy < 1 || nqz < 1 || !qx_host || !qy_host || !qz_host)
@@ -946,9 +987,9 @@ int vps_nn_resample(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const flo
   }
   if (pos_is_f64)
     return nn_run<double>(ctx, reinterpret_cast<const double*>(pos_dev), payload_dev, np, C, x0, nx, nqy,
-                          nqz, dqx, dqy, dqz, qmax, model, out_dev, nn_idx_dev, work);
+                          nqz, dqx, dqy, dqz, qmax, model, out_dev, nn_idx_dev, work, vol);
   return nn_run<float>(ctx, reinterpret_cast<const float*>(pos_dev), payload_dev, np, C, x0, nx, nqy, nqz,
-                       dqx, dqy, dqz, qmax, model, out_dev, nn_idx_dev, work);
+                       dqx, dqy, dqz, qmax, model, out_dev, nn_idx_dev, work, vol);
 }
 
 }  // extern "C"

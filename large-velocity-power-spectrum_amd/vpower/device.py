@@ -339,6 +339,22 @@ class HipKernels:
                                            x0, nx, self._ptr(out), self._ptr(idx), self._ptr(work)))
         return out, idx
 
+    def nn_resample_field(self, pos, rhov, axes, x0, nx, Lcell, out=None, want_index=False):
+        """Exact-NN resampling of [rho v, rho] with v = rho v / rho, mass = rho Lcell^3 formed in the search's
+        epilogue: -> [4, nx, ny, nz] float32 = vx, vy, vz, mass (interp.py:246-277 without a pass over the grid)."""
+        self._stream()
+        ax = [np.ascontiguousarray(a, dtype=np.float64) for a in axes]
+        if out is None:
+            out = self.empty((4, nx, len(ax[1]), len(ax[2])), torch.float32)
+        idx = self.empty((nx, len(ax[1]), len(ax[2])), torch.int32) if want_index else None
+        kind = self._pos_kind(pos)
+        work = self.workspace("nn", self.lib.vps_nn_workspace_bytes(pos.shape[0], kind, nx * len(ax[1]) * len(ax[2])))
+        self._chk(self.lib.vps_nn_resample_field(self.ctx, self._ptr(pos), kind, self._ptr(rhov, torch.float32),
+                                                 pos.shape[0], _ffi.as_dp(ax[0]), len(ax[0]), _ffi.as_dp(ax[1]), len(ax[1]),
+                                                 _ffi.as_dp(ax[2]), len(ax[2]), x0, nx, float(Lcell), self._ptr(out),
+                                                 self._ptr(idx), self._ptr(work)))
+        return out, idx
+
     def field_algebra(self, chans, quantity, flags, Lcell):
         self._stream()
         ncell = chans[0].numel()

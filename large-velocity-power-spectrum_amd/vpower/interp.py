@@ -132,8 +132,7 @@ class GasParticles:
         k = _kernels()
         Lcell = self.Lbox / Nsize
         ax = _lattice_axis(self.Lbox, Nsize)
-        grid, _ = k.nn_resample(_pos_tensor(k, self.pos), self._device_payload(k), (ax, ax, ax), 0, Nsize)
-        k.field_algebra(grid, _dev.VM, 0, Lcell)
+        grid, _ = k.nn_resample_field(_pos_tensor(k, self.pos), self._device_payload(k), (ax, ax, ax), 0, Nsize, Lcell)
         return BoxField._from_device(grid, Lcell)
 
     def deposit_to_field(self, Nsize, assignment="ngp"):
