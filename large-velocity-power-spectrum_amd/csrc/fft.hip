@@ -697,10 +697,20 @@ constexpr int pencil_min_waves() {
   return NC >= 1024 ? VPS_PENCIL_MINW_LONG : VPS_PENCIL_MINW;
 }
 
+// Lanes per line: the plan's, except for 2048-cell lines, where a line runs on HALF of them (32 lanes x 32 points): 16
+// lines -- full 128-byte output segments -- are then 512 threads instead of 1024, two waves per SIMD with a 256-VGPR
+// budget instead of four with 128 (which this kernel spills at: 88 / 292 bytes per lane).  8-line pencils on the plan's
+// lanes avoid the spills too, but their 64-byte segments only merged for 62 % of the lines even with the partner pencils
+// placed on one XCD (PMC WRITE_SIZE 142 GB for 103 GB of output at 2048^3).
+template <int NC>
+constexpr int pencil_lanes() {
+  return NC >= 1024 ? PlanInfo<NC>::L / 2 : PlanInfo<NC>::L;
+}
+
 template <int NC, int TP, bool ENERGY = false>
-__global__ void __launch_bounds__(TP* PlanInfo<NC>::L, pencil_min_waves<NC>()) pencil_fft_z_kernel(const PencilParams p) {
+__global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()) pencil_fft_z_kernel(const PencilParams p) {
   typedef PlanInfo<NC> PI;
-  constexpr int L = PI::L, RL = PI::RL, NT = TP * L, N = 2 * NC;
+  constexpr int L = pencil_lanes<NC>(), RL = NC / L, NT = TP * L, N = 2 * NC;
   constexpr int ACC = TP * N;                       // floats of one accumulator
   constexpr int LINES = TP * PI::PITCH * 2;         // floats of the exchange buffers
   constexpr int SHARED = (ACC > LINES ? ACC : LINES);
@@ -753,11 +763,11 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, pencil_min_waves<NC>()) p
     const unsigned j = s + tid + k * NT;
     rloc[k] = (j < e) ? p.records[(size_t)j * 5] : 0xffffffffu;
   }
-  fetch(p.divide ? 4 : 1 + p.chan[0]);
+  fetch((p.divide && !ENERGY) ? 4 : 1 + p.chan[0]);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int R0 = PI::R0, NB0 = RL / R0;
-  float2 scale[RL];   // per stage-0 input cell pair: 1/rho (0 where empty) or Lcell^3
-  if (p.divide) {
+  float2 scale[RL];   // per stage-0 input cell pair: 1/rho (0 where empty) or Lcell^3 (ENERGY: unused -- rho comes last)
+  if (!ENERGY && p.divide) {
     for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
     __syncthreads();
 #pragma unroll
@@ -786,7 +796,10 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, pencil_min_waves<NC>()) p
   }
 
   cf e2[ENERGY ? RL : 1];   // sum over the components of (rho v_c)^2 per stage-0 cell (ENERGY only)
-  for (int c = 0; c < p.ncomp; ++c) {
+  // ENERGY: the three rho*v_c rounds add up q_c^2, a FOURTH round accumulates rho and finishes E = vol * sum / rho -- so that
+  // the 1/rho table never has to live through the component rounds next to the sums (registers)
+  const int nround = ENERGY ? p.ncomp + 1 : p.ncomp;
+  for (int c = 0; c < nround; ++c) {
     // opaque copies: keeps the compiler from hoisting ~50 loop-invariant LDS addresses out of the
     // component loop (they cost more registers than the 1/rho table and an occupancy step)
     int lc = l, tc = t, tidc = tid;
@@ -797,14 +810,14 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, pencil_min_waves<NC>()) p
     __syncthreads();   // rho / previous component's transposed image fully consumed
     for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
     __syncthreads();
-    const int chn = p.chan[c];
+    const int word = (ENERGY && c == p.ncomp) ? 4 : 1 + p.chan[c < p.ncomp ? c : 0];
 #pragma unroll
     for (int k = 0; k < KR; ++k)
       if (rloc[k] != 0xffffffffu) vps_lds_add(&acc[rloc[k]], rval[k], crowded);
-    if (c + 1 < p.ncomp) fetch(1 + p.chan[c + 1]);
+    if (c + 1 < nround) fetch((ENERGY && c + 1 == p.ncomp) ? 4 : 1 + p.chan[c + 1 < p.ncomp ? c + 1 : 0]);
     for (unsigned j = s + tid + KR * NT; j < e; j += NT) {
       const unsigned* rec = p.records + (size_t)j * 5;
-      vps_lds_add(&acc[rec[0]], __uint_as_float(rec[1 + chn]), crowded);
+      vps_lds_add(&acc[rec[0]], __uint_as_float(rec[word]), crowded);
     }
     __syncthreads();
     // stage-0 inputs straight from the accumulator: z[j] = f[2j] + i f[2j+1]
@@ -817,26 +830,29 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, pencil_min_waves<NC>()) p
         for (int rr = 0; rr < R0; ++rr) {
           const int j = lc + L * m + rr * (NC / R0);
           const float2 qq = *reinterpret_cast<const float2*>(q + 2 * j);
-          const float2 sc = scale[m * R0 + rr];
           if constexpr (ENERGY) {
-            // kinetic energy: the three rho*v_c rounds only add up q_c^2; E = vol * sum / rho after the last
             cf& a2 = e2[m * R0 + rr];
-            a2 = (c == 0) ? make_float2(qq.x * qq.x, qq.y * qq.y) : make_float2(a2.x + qq.x * qq.x, a2.y + qq.y * qq.y);
-            if (c + 1 == p.ncomp) v[m * R0 + rr] = make_float2(a2.x * sc.x * p.vol, a2.y * sc.y * p.vol);
+            if (c < p.ncomp) {
+              a2 = (c == 0) ? make_float2(qq.x * qq.x, qq.y * qq.y) : make_float2(a2.x + qq.x * qq.x, a2.y + qq.y * qq.y);
+            } else {   // qq = rho of the two cells; empty cells give 0 (the NaN->0 rule of interp.py:329-331)
+              v[m * R0 + rr] = make_float2(qq.x != 0.f ? a2.x * __builtin_amdgcn_rcpf(qq.x) * p.vol : 0.f,
+                                           qq.y != 0.f ? a2.y * __builtin_amdgcn_rcpf(qq.y) * p.vol : 0.f);
+            }
           } else {
+            const float2 sc = scale[m * R0 + rr];
             v[m * R0 + rr] = make_float2(qq.x * sc.x, qq.y * sc.y);
           }
         }
     }
     if constexpr (ENERGY) {
-      if (c + 1 < p.ncomp) continue;   // (the barrier at the top of the loop protects the accumulator)
+      if (c + 1 < nround) continue;   // (the barrier at the top of the loop protects the accumulator)
     }
     __syncthreads();   // accumulator of this component consumed: its memory becomes FFT scratch
     constexpr bool WSYNC = (L <= 64) && (64 % L == 0);
-    fft_from_regs<NC, WSYNC>(v, buf + tc * PI::PITCH, tw, lc);
+    fft_from_regs_l<NC, L, WSYNC>(v, buf + tc * PI::PITCH, tw, lc);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RL; ++i) buf[tridx<TP>(out_index<NC>(lc, i), tc)] = v[i];
+    for (int i = 0; i < RL; ++i) buf[tridx<TP>(out_index_l<NC, L>(lc, i), tc)] = v[i];
     __syncthreads();
     const int oc = ENERGY ? 0 : c;
     cf* out = p.out[oc] + (long long)x * NC * N + y0;
@@ -851,7 +867,7 @@ __global__ void __launch_bounds__(TP* PlanInfo<NC>::L, pencil_min_waves<NC>()) p
 // (2048^3, per step of 7 fields): 16 lines with spills 111 ms, 8 lines with spills 118 ms, 8 lines without 106 ms,
 // 4 lines (32-byte segments, 3 workgroups per CU) 228 ms.
 #ifndef VPS_PENCIL_TP_LONG
-#define VPS_PENCIL_TP_LONG 8
+#define VPS_PENCIL_TP_LONG 16
 #endif
 template <int NC>
 constexpr int pencil_tp() {
@@ -878,7 +894,7 @@ int launch_pencil(vps_ctx* ctx, const PencilParams& p, long long npencils) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   {
     vps_launch_timer tm(ctx, VPS_K_FFT_Z);
-    hipLaunchKernelGGL(kern, dim3((unsigned)npencils), dim3(PENCIL_TP * PI::L), lds, ctx->stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)npencils), dim3(PENCIL_TP * pencil_lanes<NC>()), lds, ctx->stream, p);
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
   return VPS_OK;

@@ -1,17 +1,26 @@
 #!/bin/bash
-# Collects the judged profile artefacts for one round on the GPU box (run from the repo root):
-#   tools/gpu_profile_round.sh r01
-# -> gpurun_out/prof/<tag>_kernel_stats.csv, <tag>_pmc_fetch.csv, <tag>_pmc_write.csv, <tag>_bench.json
+# Collects the judged profile artefacts of a round on the GPU box (run from the repo root):
+#   tools/gpu_profile_round.sh r02
+# -> gpurun_out/prof/<tag>_bench.json          the JSON line of the default `python3 bench.py` (C4 headline + C2, C3)
+#    gpurun_out/prof/<tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the SAME command
+#    gpurun_out/prof/<tag>_pmc_fetch.csv / _pmc_write.csv / _pmc_valu.csv   three separate --pmc passes (counters only)
+# then: python3 tools/pmc_summary.py gpurun_out/prof/<tag> profiles/<tag>
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/prof
-python3 bench.py > gpurun_out/prof/${tag}_bench.json 2> gpurun_out/prof/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/${tag}_kt -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/prof/${tag}_kt.log 2>&1
+python3 bench.py > gpurun_out/prof/${tag}_bench.json 2> gpurun_out/prof/${tag}_bench.err || exit 1
+echo "bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/${tag}_kt -- python3 bench.py --no-cpu-baseline > gpurun_out/prof/${tag}_kt.log 2>&1 || exit 1
 cp $(ls gpurun_out/prof/${tag}_kt/*/*_kernel_stats.csv | head -1) gpurun_out/prof/${tag}_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/${tag}_pf -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 > gpurun_out/prof/${tag}_pf.log 2>&1
-cp $(ls gpurun_out/prof/${tag}_pf/*/*_counter_collection.csv | head -1) gpurun_out/prof/${tag}_pmc_fetch.csv
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/${tag}_pw -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 > gpurun_out/prof/${tag}_pw.log 2>&1
-cp $(ls gpurun_out/prof/${tag}_pw/*/*_counter_collection.csv | head -1) gpurun_out/prof/${tag}_pmc_write.csv
-rm -rf gpurun_out/prof/${tag}_kt gpurun_out/prof/${tag}_pf gpurun_out/prof/${tag}_pw
-head -c 1500 gpurun_out/prof/${tag}_bench.json; echo
-head -12 gpurun_out/prof/${tag}_kernel_stats.csv | cut -c1-150
+echo "kernel trace done"
+for c in FETCH_SIZE:fetch WRITE_SIZE:write "VALUBusy LDSBankConflict MemUnitStalled":valu; do
+  ctr=${c%%:*}; short=${c##*:}
+  rocprofv3 --pmc $ctr --output-format csv -d gpurun_out/prof/${tag}_p$short -- python3 bench.py --steps 1 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-parity > gpurun_out/prof/${tag}_p$short.log 2>&1 || exit 1
+  cp $(ls gpurun_out/prof/${tag}_p$short/*/*_counter_collection.csv | head -1) gpurun_out/prof/${tag}_pmc_$short.csv
+  rm -rf gpurun_out/prof/${tag}_p$short
+  echo "pmc $short done"
+done
+rm -rf gpurun_out/prof/${tag}_kt
+python3 tools/pmc_summary.py gpurun_out/prof/${tag} gpurun_out/prof/${tag}
+head -c 1200 gpurun_out/prof/${tag}_bench.json; echo
+head -14 gpurun_out/prof/${tag}_kernel_stats.csv | cut -c1-160
