@@ -439,6 +439,7 @@ constexpr int NT_T = 16;                  // lattice tile edge
 constexpr int NT_PTS = NT_T * NT_T * NT_T;
 constexpr int NT_MAXCOL = 1024;           // cell columns of a tile's search region staged in LDS
 constexpr int NT_THREADS = 256;
+constexpr int NT_SEG = 1024;              // region particles sorted by box size at a time
 
 struct NnScatterParams {
   const float4* srec;
@@ -493,6 +494,9 @@ __global__ void __launch_bounds__(NT_THREADS) nn_scatter_kernel(const F* __restr
   __shared__ float qf[3][NT_T];                 // lattice coordinates relative to the tile centre
   __shared__ unsigned wsum[4];
   __shared__ unsigned s_count;
+  __shared__ unsigned stash[NT_SEG];          // packed box (and size class) of the region particles being sorted
+  __shared__ unsigned short order[NT_SEG];    // their order, most rows first
+  __shared__ unsigned cls[65];
 
   const int tid = threadIdx.x;
   const int ntz = (p.nqz + NT_T - 1) / NT_T, nty = (p.nqy + NT_T - 1) / NT_T;
@@ -593,7 +597,12 @@ __global__ void __launch_bounds__(NT_THREADS) nn_scatter_kernel(const F* __restr
   if (tid == 0) colbase[NT_MAXCOL] = total;
   __syncthreads();
 
-  // ---- scatter: one particle per thread ----
+  // ---- scatter: one particle per thread, particles dealt out in order of their box size ----
+  // A particle's work is its (ix, iy) rows of up to 8 z-points.  Boxes differ a lot (those of the halo particles are
+  // clipped by the tile), and a wave runs as long as its biggest box: so the region's particles are first counting-sorted
+  // in LDS by their number of rows (largest first, NT_SEG particles at a time), and every wave then gets 64 particles of
+  // about the same size; the rows of a box are walked in ONE loop (ix, iy advanced together), so different box shapes
+  // with the same row count cost the same.
   float inv_h[3], a0f[3];   // index of a tile-relative coordinate v on axis a: (v - a0f) * inv_h
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -601,59 +610,105 @@ __global__ void __launch_bounds__(NT_THREADS) nn_scatter_kernel(const F* __restr
     a0f[a] = (float)(p.a0[a] + (double)((a == 0 ? p.x0 : 0) + t0[a]) * p.h[a] - org[a]);
   }
   unsigned* key32 = reinterpret_cast<unsigned*>(key);
-  for (unsigned j = tid; j < total; j += NT_THREADS) {
-    // column of item j: largest col with colbase[col] <= j
-    int a_ = 0, b_ = ncol;
+  // tile-relative position and record of flattened region particle j
+  auto fetch_particle = [&](unsigned j, float (&pr)[3], int& oi) {
+    int a_ = 0, b_ = ncol;   // column of item j: largest col with colbase[col] <= j
     while (b_ - a_ > 1) {
       const int m = (a_ + b_) >> 1;
       if (colbase[m] <= j) a_ = m; else b_ = m;
     }
     const float4 rec = srec_load(p.srec, colg0[a_] + (j - colbase[a_]));
-    const int oi = __float_as_int(rec.w);
+    oi = __float_as_int(rec.w);
     double pd[3];
     if constexpr (sizeof(F) == 4) {
       pd[0] = (double)rec.x; pd[1] = (double)rec.y; pd[2] = (double)rec.z;
     } else {
       pd[0] = pos[(long long)oi * 3 + 0]; pd[1] = pos[(long long)oi * 3 + 1]; pd[2] = pos[(long long)oi * 3 + 2];
     }
-    const float pr[3] = {(float)(pd[0] - org[0]), (float)(pd[1] - org[1]), (float)(pd[2] - org[2])};
-    // lattice indices (tile-local) whose coordinate can be within R of the particle: every integer of
-    // [(p - R - a0)/h - slack, (p + R - a0)/h + slack], slack = measured deviation of the axis from uniform
-    // (in units of h) + float32 rounding of this arithmetic
-    int i0[3], i1[3];
-    bool any = true;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float u0 = (pr[a] - Rf - a0f[a]) * inv_h[a], u1 = (pr[a] + Rf - a0f[a]) * inv_h[a];
-      const float ulo = fminf(u0, u1), uhi = fmaxf(u0, u1);
-      i0[a] = max(0, (int)ceilf(ulo - p.slack[a]));
-      i1[a] = min(nt[a] - 1, (int)floorf(uhi + p.slack[a]));
-      any = any && (i0[a] <= i1[a]);
-    }
-    if (!any) continue;
-    const unsigned long long mine_lo = (unsigned long long)(unsigned)oi;
-    // z in chunks of 8 (one chunk when 2R < 8 h, the usual case): the chunk's fz^2 stay in registers, the 8 current
-    // minima of a (ix, iy) row are read together, so the LDS latency is paid once per row, not once per pair
-    for (int zb = i0[2]; zb <= i1[2]; zb += 8) {
-      float fz2[8];
+    for (int a = 0; a < 3; ++a) pr[a] = (float)(pd[a] - org[a]);
+  };
+  for (unsigned seg0 = 0; seg0 < total; seg0 += NT_SEG) {
+    const unsigned nseg = min((unsigned)NT_SEG, total - seg0);
+    if (tid < 64) cls[tid] = 0;
+    __syncthreads();
+    // pass 1: the box of every particle of the segment -> stash, histogram of the row-count classes
+    for (unsigned jl = tid; jl < nseg; jl += NT_THREADS) {
+      float pr[3];
+      int oi;
+      fetch_particle(seg0 + jl, pr, oi);
+      // lattice indices (tile-local) whose coordinate can be within R of the particle: every integer of
+      // [(p - R - a0)/h - slack, (p + R - a0)/h + slack], slack = measured deviation of the axis from uniform
+      // (in units of h) + float32 rounding of this arithmetic
+      unsigned pk = 0;
+      bool any = true;
+      int n_[3];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float fz = qf[2][min(zb + k, NT_T - 1)] - pr[2];
-        fz2[k] = (zb + k <= i1[2]) ? fz * fz : INFINITY;     // beyond the box: never a candidate
+      for (int a = 0; a < 3; ++a) {
+        const float u0 = (pr[a] - Rf - a0f[a]) * inv_h[a], u1 = (pr[a] + Rf - a0f[a]) * inv_h[a];
+        const float ulo = fminf(u0, u1), uhi = fmaxf(u0, u1);
+        const int lo_ = max(0, (int)ceilf(ulo - p.slack[a])), hi_ = min(nt[a] - 1, (int)floorf(uhi + p.slack[a]));
+        any = any && (lo_ <= hi_);
+        n_[a] = hi_ - lo_ + 1;
+        pk |= ((unsigned)(lo_ & 15) | ((unsigned)(hi_ & 15) << 4)) << (8 * a);
       }
-      for (int ix = i0[0]; ix <= i1[0]; ++ix) {
-        const float fx = qf[0][ix] - pr[0];
-        const float fx2 = fx * fx;
-        for (int iy = i0[1]; iy <= i1[1]; ++iy) {
+      if (any) {
+        const int c_ = 63 - min(63, n_[0] * n_[1] - 1);            // class 0 = 64 or more rows
+        pk |= 0x80000000u | ((unsigned)c_ << 24);
+        atomicAdd(&cls[c_], 1u);
+      }
+      stash[jl] = pk;
+    }
+    __syncthreads();
+    if (tid < 64) {   // exclusive scan of the 64 class counts by the first wave
+      const unsigned v = cls[tid];
+      unsigned incl = v;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off, 64);
+        if (tid >= off) incl += o;
+      }
+      cls[tid] = incl - v;
+      if (tid == 63) cls[64] = incl;
+    }
+    __syncthreads();
+    const unsigned nvalid = cls[64];
+    for (unsigned jl = tid; jl < nseg; jl += NT_THREADS) {
+      const unsigned pk = stash[jl];
+      if (pk & 0x80000000u) order[atomicAdd(&cls[(pk >> 24) & 63u], 1u)] = (unsigned short)jl;
+    }
+    __syncthreads();
+    // pass 2: the scatter proper
+    for (unsigned k_ = tid; k_ < nvalid; k_ += NT_THREADS) {
+      const unsigned jl = order[k_];
+      const unsigned pk = stash[jl];
+      float pr[3];
+      int oi;
+      fetch_particle(seg0 + jl, pr, oi);
+      const int i0x = (int)(pk & 15u), i1x = (int)((pk >> 4) & 15u), i0y = (int)((pk >> 8) & 15u), i1y = (int)((pk >> 12) & 15u);
+      const int i0z = (int)((pk >> 16) & 15u), i1z = (int)((pk >> 20) & 15u);
+      const int nrows = (i1x - i0x + 1) * (i1y - i0y + 1);
+      const unsigned long long mine_lo = (unsigned long long)(unsigned)oi;
+      // z in chunks of 8 (one chunk when 2R < 8 h, the usual case): the chunk's fz^2 stay in registers, the 8 current
+      // minima of a row are read together, so the LDS latency is paid once per row, not once per pair
+      for (int zb = i0z; zb <= i1z; zb += 8) {
+        float fz2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float fz = qf[2][min(zb + k, NT_T - 1)] - pr[2];
+          fz2[k] = (zb + k <= i1z) ? fz * fz : INFINITY;     // beyond the box: never a candidate
+        }
+        int ix = i0x, iy = i0y;
+        float fx = qf[0][ix] - pr[0];
+        float fx2 = fx * fx;
+        for (int t_ = 0; t_ < nrows; ++t_) {
           const float fy = qf[1][iy] - pr[1];
           const float t2 = fx2 + fy * fy;
           const int q0 = (ix * NT_T + iy) * NT_T + zb;
-          // The 8 current minima of the row are read together (one LDS latency per row) and screened into a bit mask: a
-          // pair goes on only if it can still win or tie.  The survivors (few per lane and row) are then worked off lowest
-          // bit first, so a wave issues as many atomic instructions per row as its busiest lane has survivors, not eight.
-          // The atomic-min returns the previous key: of the final smallest and second-smallest keys whichever arrives
-          // later sees the other one, so comparing (old, mine) catches every point whose runner-up lies inside the
-          // winner's screen -- `contested`.
+          // The 8 current minima of the row are screened into a bit mask: a pair goes on only if it can still win or tie.
+          // The survivors (few per lane and row) are then worked off lowest bit first, so a wave issues as many atomic
+          // instructions per row as its busiest lane has survivors, not eight.  The atomic-min returns the previous key:
+          // of the final smallest and second-smallest keys whichever arrives later sees the other one, so comparing
+          // (old, mine) catches every point whose runner-up lies inside the winner's screen -- `contested`.
           unsigned m = 0;
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
@@ -679,11 +734,17 @@ __global__ void __launch_bounds__(NT_THREADS) nn_scatter_kernel(const F* __restr
               if (dhi <= rb * rb * 1.000001f) contested[q] = 1;
             }
           }
+          if (++iy > i1y) {            // next row of the box
+            iy = i0y;
+            ix = min(ix + 1, NT_T - 1);
+            fx = qf[0][ix] - pr[0];
+            fx2 = fx * fx;
+          }
         }
       }
     }
+    __syncthreads();   // stash / order are rewritten by the next segment
   }
-  __syncthreads();
 
   // ---- epilogue: 16 consecutive z per row leave together ----
   const long long nqs = (long long)p.nx * p.nqy * p.nqz;
