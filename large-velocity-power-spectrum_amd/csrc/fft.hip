@@ -549,7 +549,9 @@ __device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf*
 // output index k, the T results to T contiguous complex slots out[b][k][a0..].
 // ------------------------------------------------------------------------------
 // NTEMP: non-temporal loads and stores (y pass of images up to ~0.75 GB: -4..-9 % there, +2..+5 % on larger ones)
-template <int NC, int T, bool REAL, bool NTEMP = false>
+// KG: the Nyquist-plane launch of the chunked exchange (output rows shifted per destination rank, PassParams::kg) -- its own
+// instantiation, so that the main passes carry no per-element division
+template <int NC, int T, bool REAL, bool NTEMP = false, bool KG = false>
 __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
     fft_transpose_pass(const PassParams p) {
   typedef PlanInfo<NC> PI;
@@ -641,7 +643,8 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
       const int tt = idx % T, k = idx / T;
       if (a0 + tt < p.A) {
         const cf val = buf[tridx<T>(k, tt)];
-        const long long o = (long long)k * p.out_ok + (p.kg ? (long long)(k / p.kg) * p.kg_gap : 0) + tt;
+        long long o = (long long)k * p.out_ok + tt;
+        if constexpr (KG) o += (long long)(k / p.kg) * p.kg_gap;
         if constexpr (NTEMP)
           store_stream(&out[o], val);
         else
@@ -1305,6 +1308,7 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
   if constexpr (!REAL) {
     const double image_bytes = 8.0 * (double)p.A * (double)p.B * (double)NC;
     if (image_bytes <= 768.0 * 1048576.0) kern = fft_transpose_pass<NC, T, REAL, true>;
+    if (p.kg) kern = fft_transpose_pass<NC, T, REAL, true, true>;   // Nyquist plane of a chunked exchange (one small image)
   }
   if (lds > 64 * 1024)
     VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
