@@ -869,13 +869,14 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
   }
 }
 
-// y-lines per pencil: 16 (128-byte output segments); 8 for 2048-cell lines: 16 lines are 1024 threads = four waves per
-// SIMD, i.e. 128 VGPRs, which the kernel does not fit into (see pencil_min_waves); 8 lines leave the register budget open.
-// The two pencils that complete a 128-byte output line are placed on one XCD (remap in the kernel).  Measured at C4
-// (2048^3, per step of 7 fields): 16 lines with spills 111 ms, 8 lines with spills 118 ms, 8 lines without 106 ms,
-// 4 lines (32-byte segments, 3 workgroups per CU) 228 ms.
+// y-lines per pencil: 16 (128-byte output segments); 8 for 2048-cell lines, on half the plan's lanes (pencil_lanes): 256
+// threads and 76 KB of LDS per workgroup, so TWO workgroups share a CU and one's stores overlap the other's LDS work.  The two
+// pencils that complete a 128-byte output line are placed on one XCD (remap in the kernel); 38 % of the lines still
+// reach HBM as two halves (PMC WRITE_SIZE 142 GB for 103 GB of output), which costs less than the lost overlap.
+// Measured at C4 (2048^3, ms per step of 7 fields): 16 lines x 64 lanes, spilling 111; 8 x 64 spilling 118, not spilling
+// (two waves per SIMD) 106; 16 x 32 (one workgroup per CU, full-line writes) 88; 8 x 32 83; 4 x 64 (32-byte segments) 228.
 #ifndef VPS_PENCIL_TP_LONG
-#define VPS_PENCIL_TP_LONG 16
+#define VPS_PENCIL_TP_LONG 8
 #endif
 template <int NC>
 constexpr int pencil_tp() {
@@ -1108,7 +1109,8 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
           pacc[i] = (c == 0) ? a : pacc[i] + a;
         }
         // (Requesting the next line BEFORE this transform -- a second register set, affordable at 2048 where LDS limits
-        // the kernel to two waves per SIMD -- was measured at 2048^3: 73.2 against 72.5 ms per step.  Not kept.)
+        // the kernel to two waves per SIMD -- was measured at 2048^3: 73.2 against 72.5 ms per step; twiddles and shell
+        // thresholds left in L2 instead of LDS (46 KB: three workgroups per CU instead of two): 73 ms.  Not kept.)
         if (c + 1 < p.ncomp) {
           load_line(v, c + 1, lc);
         } else if (tile + gridDim.x < ntiles) {
