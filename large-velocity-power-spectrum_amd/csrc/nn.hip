@@ -7,10 +7,15 @@
 // states, so indices are bit exact.
 //
 // Method: counting-sort the particles into an M^3 cell list spanning their bounding
-// box (about two particles per cell), then one thread per lattice point searches
-// Chebyshev rings of cells around its own cell until the best squared distance is
-// provably smaller than the distance to every unsearched cell.  Lattice points are
-// z-fastest, so a wave's 64 queries walk the same few cell runs.
+// box (about 1.5 particles per cell), then
+//   * uniformly spaced lattices (both reference lattices): nn_scatter_kernel -- a 16^3 tile of
+//     lattice points keeps its running minima in LDS and every nearby particle lowers the
+//     minima inside its own R-box; the few points this cannot settle (voids, near-ties)
+//     are finished by nn_fallback_kernel;
+//   * any other lattice axes: nn_query_kernel -- one thread per lattice point, a wave-wide
+//     staged union of candidate cells, then Chebyshev rings of cells from global memory
+//     until the best squared distance is provably smaller than the distance to every
+//     unsearched cell (nn_ring_search, also the fallback's search).
 #pragma clang fp contract(off)
 
 #include <cmath>
@@ -418,8 +423,8 @@ __global__ void __launch_bounds__(256)
 // every particle within a radius R of the tile visits only the lattice points inside its own R-box
 // (about (2R/h)^3 of them) and lowers their keys with one LDS atomic-min.  Per (point, particle) pair
 // the cost is one add, one LDS read of the current minimum and a compare; the atomic runs only when the
-// pair can still win.  R follows the local density (R = kappa * n_local^(-1/3), about 9 visits per lattice
-// point at kappa = 1.3), so dense and sparse tiles do comparable work per lattice point.
+// pair can still win.  R follows the local density (R = kappa * n_local^(-1/3), kappa = 1.15: about 12 box visits, 6
+// of them inside the sphere, per lattice point), so dense and sparse tiles do comparable work per lattice point.
 //
 // Exactness (the oracle's rule: smallest float64 squared distance, lowest index on ties):
 //   * distances are evaluated in float32 on coordinates taken RELATIVE TO THE TILE CENTRE (subtracted in
@@ -432,7 +437,7 @@ __global__ void __launch_bounds__(256)
 //     point is marked `contested`;
 //   * a point is `resolved` when its winner's distance is provably <= R: every particle within R has
 //     visited it (the R-box of a particle covers its R-ball).
-// Unresolved or contested points (voids, near-ties, duplicates: ~1e-4 of the points on the BASELINE configs) are
+// Unresolved or contested points (voids, near-ties, duplicates: 2e-3 of the points at C3 with kappa = 1.15) are
 // appended to a list and finished by nn_fallback_kernel with the exact float64 ring search.
 // ------------------------------------------------------------------------------------------------
 constexpr int NT_T = 16;                  // lattice tile edge
