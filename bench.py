@@ -147,7 +147,18 @@ class Workload:
         maxc = max(NCOMP[q] for q in self.quantities)
         if route == "ngp":
             self.fused = (not unfused) and all(K.fused_supported(N, device.QUANTITY[q]) for q in self.quantities)
-            if self.fused and self.pipe.chunked:
+            # Several ranks, several quantities: the quantities are pipelined -- quantity q+1's deposit + z pass is issued while
+            # q's chunks are still crossing the node, q's x passes run after it.  Needs a z image per quantity and two
+            # quantities' send / receive buffers at a time: on from 4 ranks (2 ranks of C4 would need > 288 GB), or
+            # VPS_PIPELINE_QUANTITIES=1 / 0.
+            env = os.environ.get("VPS_PIPELINE_QUANTITIES")
+            self.pipelined = (self.pipe.chunked and len(self.quantities) > 1
+                              and all(K.fused_supported(N, device.QUANTITY[q]) for q in self.quantities) and not unfused
+                              and ((comm.world >= 4) if env is None else env == "1"))
+            if self.pipelined:
+                self.zimg_q = [K.empty((NCOMP[q], K.zimage_elems(N, nx)), torch.complex64) for q in self.quantities]
+                self.acc_q = [self.pipe.new_accumulators() for _ in self.quantities]
+            elif self.fused and self.pipe.chunked:
                 self.zimg = K.empty((maxc, K.zimage_elems(N, nx)), torch.complex64)
             elif self.fused:
                 self.spec = K.empty((maxc, N // 2, N, nx), torch.complex64)
@@ -174,6 +185,8 @@ class Workload:
 
     def describe_path(self):
         if self.route == "ngp":
+            if getattr(self, "pipelined", False):
+                return "fused deposit+z pass (pencil buckets); quantities pipelined against each other's exchanges"
             return "fused deposit+z pass (pencil buckets)" if self.fused else "deposit -> grid -> z pass"
         if self.route == "nn":
             return "exact-NN resample (library lattice) with v, m formed in its epilogue -> z pass (p = v*m formed in the pass)"
@@ -187,6 +200,24 @@ class Workload:
     def step(self):
         K, dev, N, L, nx, x0 = self.K, self.dev, self.N, self.L, self.nx, self.x0
         out = {}
+        if self.route == "ngp" and getattr(self, "pipelined", False):
+            token, prev = None, None
+            for i, q in enumerate(self.quantities):
+                ps, ns = self.acc_q[i]
+                ps.zero_()
+                ns.zero_()
+                z = K.deposit_fft_z(self.pos, self.vel, self.rho, N, L, x0, nx, dev.QUANTITY[q], zimg=self.zimg_q[i], reuse_sort=token)
+                token = K.fused_token()
+                started = self.pipe.start_zimages([z[c] for c in range(NCOMP[q])])
+                if prev is not None:                       # bin the previous quantity while this one's chunks travel
+                    self.pipe.finish_zimages(prev[1], *self.acc_q[prev[0]])
+                prev = (i, started)
+            self.pipe.finish_zimages(prev[1], *self.acc_q[prev[0]])
+            for i, q in enumerate(self.quantities):
+                tab = self.pipe.finish(*self.acc_q[i])
+                tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2
+                out[q] = tab
+            return out
         if self.route == "ngp":
             token = None
             for q in self.quantities:
@@ -301,6 +332,11 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     from vpower import device, synth
     N, Np, off = synth.CONFIGS[cfg]
     route, quantities, flavour = synth.WORKLOADS[cfg]
+    rehearsal = None
+    if os.environ.get("VPS_BENCH_GRID"):       # rehearsal of a config's code path at a size that fits the box (never a result)
+        N = int(os.environ["VPS_BENCH_GRID"])
+        Np = int(float(os.environ.get("VPS_BENCH_PARTICLES", Np)))
+        rehearsal = "REHEARSAL at %d^3 / %d particles (VPS_BENCH_GRID): not the config's size" % (N, Np)
     L = 1.0
     G = comm.world
     lognormal = cfg != "C1"      # C1 follows the script, which ignores densities
@@ -388,7 +424,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
         "ms_per_step": ms_per_step,
         "value": cells * steps / dt,
         "config": {"workload": "%s: %s" % (cfg, cfg_text),
-                   "deviation": ("strong-scaled over %d GPU(s) of one node" % world) if cfg in ("C4", "C5") and world != 8 else None,
+                   "deviation": rehearsal or (("strong-scaled over %d GPU(s) of one node" % world) if cfg in ("C4", "C5") and world != 8 else None),
                    "grid": N, "particles": Np, "route": route, "quantities": list(quantities),
                    "scalar_fields_per_step": nfields, "path": wl.describe_path(),
                    "parallelism": ("x-slab x%d, one message per field and pair of ranks in %d kz chunks (Nyquist rows inside it)"

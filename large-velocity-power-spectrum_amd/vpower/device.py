@@ -673,10 +673,24 @@ class PowerPipeline:
             c -= 1
         return max(c, 1)
 
-    def accumulate_zimages(self, zimgs, psum=None, nsample=None, count=True):
-        """x-side of the transform for z images (HipKernels.fft_z / deposit_fft_z): per kz chunk, y pass into the
-        send buffer, all-to-all started at once, then -- as chunks arrive -- x pass + shell sums.  Up to three
-        components share one binning launch per chunk (their |F|^2 are summed before the shell search)."""
+    def start_zimages(self, zimgs):
+        """First half of `accumulate_zimages`: per group of up to three components and per kz chunk, the y pass into
+        the send buffer and the all-to-all, all started asynchronously.  Returns what `finish_zimages` needs.  Between
+        the two calls the caller may enqueue other work (the next quantity's deposit + z pass): it overlaps the exchanges."""
+        N, nx, G = self.N, self.nx, self.comm.world
+        k = self.k
+        C_ = self.nchunks
+        group = 1 if os.environ.get("VPS_X_PER_COMPONENT") == "1" else 3
+        started = []
+        for i in range(0, len(zimgs), group):
+            comps = zimgs[i:i + group]
+            started.append([[self.comm.all_to_all_start(k.fft_y_chunk(z, N, nx, G, C_, c)) for z in comps]
+                            for c in range(C_)])
+        return started
+
+    def finish_zimages(self, started, psum=None, nsample=None, count=True):
+        """Second half: as the chunks arrive, x pass + shell sums (up to three components share one binning launch per
+        chunk: their |F|^2 are summed before the shell search)."""
         N, nx, G, r = self.N, self.nx, self.comm.world, self.comm.rank
         k = self.k
         k.set_binning(*self._binning)
@@ -686,14 +700,9 @@ class PowerPipeline:
         C_ = self.nchunks
         nkz, nky = N // 2 // G, N // G
         nkc = nkz // C_
-        group = 1 if os.environ.get("VPS_X_PER_COMPONENT") == "1" else 3
-        for i in range(0, len(zimgs), group):
-            comps = zimgs[i:i + group]
+        for i, pending in enumerate(started):
             cnt = count and i == 0
-            pending = []
-            for c in range(C_):                      # y passes and exchanges are issued chunk by chunk ...
-                pending.append([self.comm.all_to_all_start(k.fft_y_chunk(z, N, nx, G, C_, c)) for z in comps])
-            for c in range(C_):                      # ... and binned in the same order, as they complete
+            for c in range(C_):
                 recvs = [self.comm.all_to_all_finish(h) for h in pending[c]]
                 pending[c] = None
                 last = c == C_ - 1
@@ -702,6 +711,15 @@ class PowerPipeline:
                 if last:
                     nyqs = [t[nkc * N * nx:] for t in recvs]
                     k.fft_x_bin_multi(nyqs, N, nky, r * nky, N // 2, G, blk, psum, nsample, count=cnt)
+        return psum, nsample
+
+    def accumulate_zimages(self, zimgs, psum=None, nsample=None, count=True):
+        """x-side of the transform for z images (HipKernels.fft_z / deposit_fft_z): per kz chunk, y pass into the
+        send buffer, all-to-all started at once, then -- as chunks arrive -- x pass + shell sums."""
+        group = 1 if os.environ.get("VPS_X_PER_COMPONENT") == "1" else 3
+        for i in range(0, len(zimgs), group):      # one group in flight at a time (send + receive buffers of 3 fields)
+            psum, nsample = self.finish_zimages(self.start_zimages(zimgs[i:i + group]), psum, nsample,
+                                                count=count and i == 0)
         return psum, nsample
 
     # -- stage B + C on one or more real fields of this rank's slab ---------------
