@@ -1308,7 +1308,8 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
   // transform and store where only ONE workgroup fits a CU -- measured at 2048^3: at the plan's 1024 threads the 32
   // prefetch registers spill (128-VGPR cap); on half the lanes per line (512 threads, 256 VGPRs, wave-level exchanges)
   // still 124 bytes per lane of scratch and 164 ms per step of y passes against 113 ms for this kernel.  This kernel itself
-  // on half the lanes (512 threads, 197 VGPRs, no spill, wave-level exchanges): 121.5 against 115.6 ms.  Not kept.)
+  // on half the lanes (512 threads, 197 VGPRs, no spill, wave-level exchanges): 121.5 against 115.6 ms.  The persistent
+  // form at the plan's 1024 threads with the lane indices re-materialised per tile (117 VGPRs, no spill): 137.9 ms.  Not kept.)
   constexpr int T = (NC == 1024 && !REAL) ? 16 : transpose_T<NC>();
   typedef PlanInfo<NC> PI;
   const size_t lds = transpose_lds_bytes<NC, T>();
