@@ -301,23 +301,26 @@ class HipKernels:
         if nyq is None:
             nyq = self.empty((ncomp, N, nx), torch.complex64)
         work = self.workspace("fused", self.lib.vps_deposit_fft_zy_workspace_bytes(pos.shape[0], N, nx))
-        # reuse_sort (a token returned by an earlier call): several quantities of the SAME particle tensors -- the
-        # bucketed records of that call are still in the workspace if nothing else has used it since, and then
-        # only the first call sorts.  The token holds WEAK references to the tensors (a freed tensor whose address
-        # is recycled cannot pass for the old one, and nothing is kept alive by the library) and records their
-        # in-place modification counters; any mismatch silently sorts again.
-        state = (weakref.ref(pos), weakref.ref(vel), weakref.ref(rho), pos._version, vel._version, rho._version,
-                 int(N), float(Lbox), int(x0), int(nx), work.data_ptr())
-        last = getattr(self, "_fused_token", None)
-        if (reuse_sort is not None and reuse_sort is last
-                and all(r() is t for r, t in zip(last[:3], (pos, vel, rho))) and last[3:] == state[3:]):
-            flags |= FLAG_REUSE_SORT
-        self._fused_token = state
+        flags |= self._reuse_flag(reuse_sort, pos, vel, rho, N, Lbox, x0, nx, work)
         self._chk(self.lib.vps_deposit_fft_zy(self.ctx, self._ptr(pos), self._pos_kind(pos),
                                               self._ptr(vel, torch.float32), self._ptr(rho, torch.float32),
                                               pos.shape[0], N, float(Lbox), x0, nx, quantity, flags,
                                               self._ptr(spec), self._ptr(nyq), self._ptr(work)))
         return spec, nyq
+
+    def _reuse_flag(self, reuse_sort, pos, vel, rho, N, Lbox, x0, nx, work):
+        """FLAG_REUSE_SORT if `reuse_sort` (a token returned by an earlier fused call) proves that the bucketed records
+        of that call are still in `work`: several quantities of the SAME particle tensors then sort only once.  The
+        token holds WEAK references to the tensors (a freed tensor whose address is recycled cannot pass for the old
+        one, and nothing is kept alive by the library) and their in-place modification counters; any mismatch silently
+        sorts again.  Records the token of THIS call."""
+        state = (weakref.ref(pos), weakref.ref(vel), weakref.ref(rho), pos._version, vel._version, rho._version,
+                 int(N), float(Lbox), int(x0), int(nx), work.data_ptr())
+        last = getattr(self, "_fused_token", None)
+        ok = (reuse_sort is not None and reuse_sort is last
+              and all(r() is t for r, t in zip(last[:3], (pos, vel, rho))) and last[3:] == state[3:])
+        self._fused_token = state
+        return FLAG_REUSE_SORT if ok else 0
 
     def fused_token(self):
         """Token of the last deposit_fft_zy call (pass it as reuse_sort= to the next one)."""
@@ -441,13 +444,7 @@ class HipKernels:
         if zimg is None:
             zimg = self.empty((ncomp, self.zimage_elems(N, nx)), torch.complex64)
         work = self.workspace("fused_z", self.lib.vps_deposit_fft_z_workspace_bytes(pos.shape[0], N, nx))
-        state = (weakref.ref(pos), weakref.ref(vel), weakref.ref(rho), pos._version, vel._version, rho._version,
-                 int(N), float(Lbox), int(x0), int(nx), work.data_ptr())
-        last = getattr(self, "_fused_token", None)
-        if (reuse_sort is not None and reuse_sort is last
-                and all(r() is t for r, t in zip(last[:3], (pos, vel, rho))) and last[3:] == state[3:]):
-            flags |= FLAG_REUSE_SORT
-        self._fused_token = state
+        flags |= self._reuse_flag(reuse_sort, pos, vel, rho, N, Lbox, x0, nx, work)
         self._chk(self.lib.vps_deposit_fft_z(self.ctx, self._ptr(pos), self._pos_kind(pos),
                                              self._ptr(vel, torch.float32), self._ptr(rho, torch.float32),
                                              pos.shape[0], N, float(Lbox), x0, nx, quantity, flags,
