@@ -1002,21 +1002,39 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   double k2half = 0.0;
   if constexpr (MODE == 0) k2half = p.k2[NC / 2];
   cf v[RL];
+  // PAIR tiles whose smallest |ky| already puts every mode of the tile beyond the last shell edge -- fl(ky^2 + kz^2) >=
+  // thr[nbins], and s = (kx^2 + ky^2) + kz^2 can only be larger -- are neither loaded nor transformed: with the default
+  // k range (kmax = Nyquist) that is the quarter of each kz plane outside the inscribed circle (1 - pi/4 = 21 %).
+  // (The |ky| order of a plane's tiles is rotated from plane to plane: a persistent workgroup takes every gridDim-th
+  // tile, and without the rotation the same workgroups would always draw the skipped outer |ky| and the others never.)
+  constexpr long long tiles_per_plane = (NC / T) > 0 ? (NC / T) : 1;
+  auto tile_q = [&](long long tile) -> int {   // which group of TH |ky| values PAIR tile `tile` holds
+    const long long plane = tile / tiles_per_plane;
+    return (int)((tile % tiles_per_plane + plane * 619) % tiles_per_plane);
+  };
+  auto tile_beyond_shells = [&](long long tile) -> bool {
+    if constexpr (MODE == 0 && FAST) {
+      if (pair) {
+        const int kz = p.kz0 + (int)(p.line0 / p.N) + (int)(tile / tiles_per_plane);
+        return (p.k2[tile_q(tile) * TH] + p.k2[kz]) >= p.thr[p.nbins];
+      }
+    }
+    return false;
+  };
   auto locate_line = [&](long long tile) {
     li = tile * T + t;       // local line index
     mirrored = false;        // this line is the N-ky partner of line t - 1
     has_partner = false;     // line t + 1 holds this line's N-ky partner
     if (pair) {
-      constexpr long long tiles_per_plane = (NC / T) > 0 ? (NC / T) : 1;
       const long long plane = tile / tiles_per_plane;
-      const int q = (int)(tile % tiles_per_plane);
+      const int q = tile_q(tile);
       const int ky_a = q * TH + (t >> 1);
       const int ky = ((t & 1) == 0) ? ky_a : (ky_a == 0 ? NC / 2 : NC - ky_a);
       li = plane * NC + ky;
       mirrored = ((t & 1) == 1) && (ky_a != 0);
       has_partner = ((t & 1) == 0) && (ky_a != 0);
     }
-    live = li < p.nlines;
+    live = li < p.nlines && !tile_beyond_shells(tile);
     if constexpr (MODE == 0) {
       if (live) {
         const long long g = p.line0 + li;
@@ -1058,6 +1076,13 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
     load_line(v, 0, l);
   }
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (tile_beyond_shells(tile)) {   // (uniform over the workgroup) nothing to bin here: only keep the prefetch chain going
+      if (tile + gridDim.x < ntiles) {
+        locate_line(tile + gridDim.x);
+        load_line(v, 0, l);
+      }
+      continue;
+    }
     // line bookkeeping of THIS tile (v already holds, or is receiving, its inputs)
     const long long li_cur = li;
     const bool live_cur = live, mirrored_cur = mirrored, partner_cur = has_partner;
