@@ -229,10 +229,13 @@ class Workload:
                     token = K.fused_token()
                     self.pipe.accumulate_zimages([z[i] for i in range(nc)], self.psum, self.nsample)
                 elif self.fused:
-                    # deposit + field algebra + z pass in one kernel (pencil buckets), then the y passes;
+                    # deposit + field algebra + z pass in one kernel (pencil buckets), then the y passes (their output goes
+                    # straight into the binning x pass: rows beyond the last shell edge are not stored);
                     # the second and third quantity of a step reuse the first one's bucket sort
-                    spec, nyq = K.deposit_fft_zy(self.pos, self.vel, self.rho, N, L, x0, nx, qi,
-                                                 spec=self.spec[:nc], nyq=self.nyq[:nc], reuse_sort=token)
+                    self.pipe.prepare()
+                    with K.binning_only():
+                        spec, nyq = K.deposit_fft_zy(self.pos, self.vel, self.rho, N, L, x0, nx, qi,
+                                                     spec=self.spec[:nc], nyq=self.nyq[:nc], reuse_sort=token)
                     token = K.fused_token()
                     self.pipe.accumulate_spectra(spec, nyq, self.psum, self.nsample)
                 else:
@@ -353,6 +356,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     wl = Workload(K, comm, N, L, route, quantities, flavour, dpos, dvel, drho, unfused=args.unfused)
     nx = wl.nx
     nchunks = wl.pipe.nchunks
+    wl_keep = wl.pipe.kept_row_fraction(comm.rank * (N // 2 // G), (comm.rank + 1) * (N // 2 // G)) if G > 1 else wl.pipe.kept_row_fraction()
     nkz, nky, NH = N // 2 // G, N // G, N // 2
     nfields = wl.fields_per_step()
 
@@ -391,8 +395,10 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
         return v[v * 8.0 >= v.max()] if len(v) else v
     main = {"fft_y": main_of(per["fft_y"]), "fft_x": main_of(per["fft_x"]), "fft_z": per["fft_z"], "nn_query": per["nn_query"]}
     Nps = Np / G      # particles inside one rank's slab (uniform positions)
-    # algorithmic HBM bytes of the main launches of ONE step, per kernel family (DESIGN.md "Kernels")
-    step_bytes = {"fft_y": nfields * 16.0 * nx * N * NH, "fft_x": nfields * 8.0 * nkz * N * N}
+    # algorithmic HBM bytes of the main launches of ONE step, per kernel family (DESIGN.md "Kernels"): what the kernels
+    # have to move -- rows (ky, kz) beyond the last shell edge are neither written by the y pass nor read by the x pass
+    keep = wl_keep
+    step_bytes = {"fft_y": nfields * 8.0 * nx * N * NH * (1.0 + keep), "fft_x": nfields * 8.0 * nkz * N * N * keep}
     if route == "ngp" and wl.fused:
         step_bytes["fft_z"] = sum(NCOMP[q] * 8.0 * nx * N * (NH + 1) + 20.0 * Nps for q in quantities)
     else:
@@ -406,7 +412,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     dom = max(kms, key=lambda k: kms[k])
     ach = step_bytes[dom] / (kms[dom] * 1e-3) / 1e9
     fft_ms = sum(step_kernel_ms.get(k, 0.0) for k in ("fft_z", "fft_y", "fft_x"))
-    fft_bytes = step_bytes["fft_z"] + nfields * (16.0 * nx * N * (NH + 1) + 8.0 * (nkz * N + nky) * N)
+    fft_bytes = step_bytes["fft_z"] + nfields * (8.0 * nx * N * (NH + 1) * (1.0 + keep) + 8.0 * (nkz * N + nky) * N * keep)
     grid_ms = step_kernel_ms.get("deposit", 0.0) + step_kernel_ms.get("algebra", 0.0) \
         + step_kernel_ms.get("nn_build", 0.0) + step_kernel_ms.get("nn_query", 0.0)
     traffic = None
@@ -444,6 +450,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
                      "avg_launch_ms": kms[dom] / launches_per_step[dom],
                      "launches_per_step": launches_per_step[dom]},
         "per_kernel_frac_of_hbm_peak": {k: step_bytes[k] / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS for k in kms},
+        "kept_row_fraction": keep,
     }
     finite = all(np.isfinite(t[:, 2]).all() and t[:, 3].sum() > 0 for t in tabs.values())
     if rank == 0 and not os.environ.get("VPS_BENCH_NOCHECK"):      # (timing-only kernel variants produce garbage)

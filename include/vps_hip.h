@@ -214,6 +214,13 @@ int vps_fft_supported(int N);
 int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host,
                     const double* thr_host, int nbins, double edge0, double inv_spacing);
 
+/* Binning-only consumers: while `on`, the y passes (vps_fft_zy, vps_fft_zy_weighted, vps_deposit_fft_zy, vps_fft_y) do
+ * not store rows (ky, kz) all of whose modes lie beyond the last shell edge of the current vps_set_binning tables --
+ * fl(ky^2 + kz^2) >= thr[nbins]; with the default k range a fifth of the half spectrum -- and leave that memory untouched;
+ * the binning x passes (vps_fft_x modes 0 / 3, vps_fft_x_bin) never read them.  Switch it off (the default) before any
+ * call whose output is read in full (vps_fft_x modes 1, 2; vps_rfft3 and vps_power_grid do so themselves). */
+int vps_set_bin_only(vps_ctx* ctx, int on);
+
 /* Deconvolution of a mass-assignment window in the binning x pass (extension; the reference has no
  * higher-order assignment): inv_w2_axis_host[N] (float32, indexed like k2_axis, even in k) holds 1 / W(k)^2 of ONE axis,
  * W(k) = sinc(pi k / (2 k_Nyquist))^p with p = 1 (NGP), 2 (CIC), 3 (TSC); every |F(k)|^2 that vps_fft_x (modes 0, 3) and

@@ -85,6 +85,7 @@ int vps_destroy(vps_ctx* ctx) {
   if (ctx->d_axes) (void)hipFree(ctx->d_axes);
   if (ctx->d_xpart) (void)hipFree(ctx->d_xpart);
   if (ctx->d_win) (void)hipFree(ctx->d_win);
+  if (ctx->d_kcut) (void)hipFree(ctx->d_kcut);
   for (auto& l : ctx->launches) {
     (void)hipEventDestroy(l.start);
     (void)hipEventDestroy(l.stop);
@@ -244,6 +245,21 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
   VPS_HIP_CHECK(ctx, hipMalloc(&ctx->d_thr, sizeof(double) * (nbins + 1)));
   VPS_HIP_CHECK(ctx, hipMemcpy(ctx->d_k2, k2_axis_host, sizeof(double) * N, hipMemcpyHostToDevice));
   VPS_HIP_CHECK(ctx, hipMemcpy(ctx->d_thr, thr_host, sizeof(double) * (nbins + 1), hipMemcpyHostToDevice));
+  // per kz plane: the largest |ky| index that the binning x pass can still read (a mode is beyond the last shell edge when
+  // fl(ky^2 + kz^2) >= thr[nbins]; x-pass tiles hold up to 16 consecutive |ky|, hence the round-up)
+  if (ctx->d_kcut) VPS_HIP_CHECK(ctx, hipFree(ctx->d_kcut));
+  ctx->d_kcut = nullptr;
+  if (fast && N >= 128) {
+    std::vector<int> kcut(N / 2 + 1);
+    for (int kz = 0; kz <= N / 2; ++kz) {
+      int kc = -1;
+      for (int ky = 0; ky <= N / 2; ++ky)
+        if (!(k2_axis_host[ky] + k2_axis_host[kz] >= thr_host[nbins])) kc = ky;
+      kcut[kz] = kc < 0 ? -1 : ((kc | 15) < N / 2 ? (kc | 15) : N / 2);
+    }
+    VPS_HIP_CHECK(ctx, hipMalloc(&ctx->d_kcut, sizeof(int) * kcut.size()));
+    VPS_HIP_CHECK(ctx, hipMemcpy(ctx->d_kcut, kcut.data(), sizeof(int) * kcut.size(), hipMemcpyHostToDevice));
+  }
   ctx->h_k2.assign(k2_axis_host, k2_axis_host + N);
   ctx->h_thr.assign(thr_host, thr_host + nbins + 1);
   ctx->bin_fast = fast;
@@ -251,6 +267,12 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
   ctx->nbins = nbins;
   ctx->edge0 = edge0;
   ctx->inv_spacing = inv_spacing;
+  return VPS_OK;
+}
+
+int vps_set_bin_only(vps_ctx* ctx, int on) {
+  VPS_ENTER(ctx);
+  ctx->bin_only = on != 0;
   return VPS_OK;
 }
 

@@ -494,6 +494,10 @@ struct PassParams {
   // destination's rows land behind that destination's block
   int kg;
   long long kg_gap;
+  // binning-only consumers (vps_set_bin_only): rows ky with min(ky, NC - ky) > kcut[kz] are not stored -- every mode
+  // there lies beyond the last shell edge and the binning x pass does not read them.  kz = kz_fixed, or the input batch
+  const int* kcut;
+  int kz_fixed;
 };
 
 // Non-temporal (streaming) access to one complex value: data that is written once for the next pass
@@ -642,11 +646,12 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
 
   cf* out = reinterpret_cast<cf*>(p.out) + (long long)bo * p.out_ob + ogap + a0;
   if constexpr (!REAL) {
+    const int kc = p.kcut ? p.kcut[p.kz_fixed >= 0 ? p.kz_fixed : (int)b] : NC;
 #pragma unroll 4
     for (int i = 0; i < RL; ++i) {
       const int idx = tid + i * NT;
       const int tt = idx % T, k = idx / T;
-      if (a0 + tt < p.A) {
+      if (a0 + tt < p.A && min(k, NC - k) <= kc) {
         const cf val = buf[tridx<T>(k, tt)];
         long long o = (long long)k * p.out_ok + tt;
         if constexpr (KG) o += (long long)(k / p.kg) * p.kg_gap;
@@ -1744,6 +1749,8 @@ int vps_fft_y(vps_ctx* ctx, int N, int nx, const void* zimg_dev, int G, int nchu
   py.b_off = chunk * nkc;
   py.bg_in = nkz;
   py.bg_gap = last ? (long long)nky * nx : 0;
+  py.kcut = (ctx->bin_only && ctx->bin_N == N) ? ctx->d_kcut : nullptr;
+  py.kz_fixed = -1;
   rc = route_transpose(ctx, N, 0, py, VPS_K_FFT_Y);
   if (rc || !last) return rc;
   // Nyquist plane: ky rows of destination h go behind that destination's kz rows
@@ -1759,6 +1766,8 @@ int vps_fft_y(vps_ctx* ctx, int N, int nx, const void* zimg_dev, int G, int nchu
   pn.tw_stage = ty.tw_stage;
   pn.kg = nky;
   pn.kg_gap = blk - (long long)nky * nx;
+  pn.kcut = py.kcut;
+  pn.kz_fixed = NH;
   return route_transpose(ctx, N, 0, pn, VPS_K_FFT_Y);
 }
 
@@ -1780,9 +1789,12 @@ static int fft_y_of(vps_ctx* ctx, int N, int nx, const cf* B, const cf* BN, void
   py.A = nx;
   py.B = NH;
   py.tw_stage = ty.tw_stage;
+  py.kcut = (ctx->bin_only && ctx->bin_N == N) ? ctx->d_kcut : nullptr;
+  py.kz_fixed = -1;
   rc = route_transpose(ctx, N, 0, py, VPS_K_FFT_Y);
   if (rc) return rc;
   PassParams pn = py;
+  pn.kz_fixed = NH;
   pn.in = BN;
   pn.out = nyq_dev;
   pn.in_sa = N;
@@ -1932,7 +1944,10 @@ int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, d
   char* w = reinterpret_cast<char*>(work_dev);
   cf* spec = reinterpret_cast<cf*>(w + half);
   cf* nyq = spec + (size_t)(N / 2) * N * N;
+  const bool keep = ctx->bin_only;   // binned right away: modes beyond the last shell edge need not be stored
+  ctx->bin_only = true;
   int rc = vps_fft_zy(ctx, N, N, field_dev, spec, nyq, w);
+  ctx->bin_only = keep;
   if (rc) return rc;
   rc = vps_fft_x(ctx, N, (int64_t)(N / 2) * N, 0, 0, spec, 1, 0, 0, psum_dev, nsample_dev, nullptr);
   if (rc) return rc;
@@ -1946,7 +1961,10 @@ int vps_rfft3(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, void*
   char* w = reinterpret_cast<char*>(work_dev);
   cf* spec = reinterpret_cast<cf*>(w + half);
   cf* nyq = spec + (size_t)(N / 2) * N * N;
+  const bool keep = ctx->bin_only;   // every mode is wanted here: no store cut in the y pass
+  ctx->bin_only = false;
   int rc = vps_fft_zy(ctx, N, N, field_dev, spec, nyq, w);
+  ctx->bin_only = keep;
   if (rc) return rc;
   cf* out = reinterpret_cast<cf*>(out_dev);
   rc = vps_fft_x(ctx, N, (int64_t)(N / 2) * N, 0, 0, spec, 1, 0, 1, nullptr, nullptr, out);
@@ -1961,7 +1979,10 @@ int vps_power_grid(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, 
   char* w = reinterpret_cast<char*>(work_dev);
   cf* spec = reinterpret_cast<cf*>(w + half);
   cf* nyq = spec + (size_t)(N / 2) * N * N;
+  const bool keep = ctx->bin_only;   // every mode is wanted here: no store cut in the y pass
+  ctx->bin_only = false;
   int rc = vps_fft_zy(ctx, N, N, field_dev, spec, nyq, w);
+  ctx->bin_only = keep;
   if (rc) return rc;
   rc = vps_fft_x(ctx, N, (int64_t)(N / 2) * N, 0, 0, spec, 1, 0, 2, nullptr, nullptr, power_dev);
   if (rc) return rc;

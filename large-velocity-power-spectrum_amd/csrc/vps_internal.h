@@ -38,6 +38,11 @@ struct vps_ctx {
   bool bin_fast = false;    // k2 table symmetric and monotone: mirrored-kx binning is valid
   std::vector<double> h_k2, h_thr;  // host copies, to skip re-uploading identical tables
 
+  // y-pass store cut for binning-only consumers (vps_set_bin_only): kcut[kz] = largest |ky| index whose modes can still reach
+  // a shell, rounded up to the x pass's tile granularity; -1: none
+  int* d_kcut = nullptr;
+  bool bin_only = false;
+
   // 1 / W(k)^2 per axis index of the mass-assignment window (vps_set_window); NULL: no deconvolution
   float* d_win = nullptr;
   int win_N = 0;

@@ -61,6 +61,7 @@ SYMBOLS = (
     ("vps_field_algebra_out", C.c_int, (_vp, C.c_int, C.c_int, C.c_double, _vp, _i64, _vp)),
     ("vps_fft_supported", C.c_int, (C.c_int,)),
     ("vps_set_binning", C.c_int, (_vp, C.c_int, _dp, _dp, C.c_int, C.c_double, C.c_double)),
+    ("vps_set_bin_only", C.c_int, (_vp, C.c_int)),
     ("vps_set_window", C.c_int, (_vp, C.c_int, _vp)),
     ("vps_assign_expand", C.c_int, (_vp, _vp, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_double, C.c_int, _vp, _vp)),
     ("vps_fft_workspace_bytes", C.c_size_t, (C.c_int, C.c_int)),

@@ -385,6 +385,20 @@ class HipKernels:
         self._chk(self.lib.vps_set_binning(self.ctx, N, _ffi.as_dp(k2), _ffi.as_dp(thr), len(thr) - 1,
                                            float(edge0), float(inv_spacing)))
 
+    def binning_only(self):
+        """Context manager: inside it the y passes skip rows whose modes all lie beyond the last shell edge of the
+        binning tables set last (vps_set_bin_only) -- for outputs that go straight into the binning x pass."""
+        k = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                k._chk(k.lib.vps_set_bin_only(k.ctx, 1))
+
+            def __exit__(self_inner, *exc):
+                k._chk(k.lib.vps_set_bin_only(k.ctx, 0))
+                return False
+        return _Scope()
+
     def set_window(self, N, table):
         """1/W^2 axis table (window_inv2_axis) for the binning x pass, or None to switch deconvolution off."""
         self._stream()
@@ -670,6 +684,32 @@ class PowerPipeline:
             c -= 1
         return max(c, 1)
 
+    def kept_row_fraction(self, kz_lo=0, kz_hi=None):
+        """Fraction of the (ky, kz) rows of kz planes [kz_lo, kz_hi) that the binning passes keep: a row whose modes all
+        lie beyond the last shell edge -- fl(ky^2 + kz^2) >= thr[nbins] -- is neither stored by the y pass nor read by
+        the x pass (same rule and 16-row rounding as vps_set_binning's cut table; 1.0 for N < 128)."""
+        N = self.N
+        kz_hi = N // 2 if kz_hi is None else kz_hi
+        if N < 128:
+            return 1.0
+        k2h = self.k2[: N // 2 + 1]
+        kept = 0
+        for kz in range(kz_lo, kz_hi):
+            ok = np.nonzero(~((k2h + self.k2[kz]) >= self.thr[-1]))[0]
+            if len(ok):
+                kc = min(int(ok[-1]) | 15, N // 2)
+                kept += min(2 * kc + 1, N)
+        return kept / float(N * max(kz_hi - kz_lo, 1))
+
+    def prepare(self):
+        """Upload this pipeline's binning (and window) tables; `self.k.binning_only()` scopes refer to them."""
+        self.k.set_binning(*self._binning)
+        self._set_window()
+
+    def _bin_scope(self):
+        import contextlib
+        return self.k.binning_only() if hasattr(self.k, "binning_only") else contextlib.nullcontext()
+
     def start_zimages(self, zimgs):
         """First half of `accumulate_zimages`: per group of up to three components and per kz chunk, the y pass into
         the send buffer and the all-to-all, all started asynchronously.  Returns what `finish_zimages` needs.  Between
@@ -679,10 +719,12 @@ class PowerPipeline:
         C_ = self.nchunks
         group = 1 if os.environ.get("VPS_X_PER_COMPONENT") == "1" else 3
         started = []
-        for i in range(0, len(zimgs), group):
-            comps = zimgs[i:i + group]
-            started.append([[self.comm.all_to_all_start(k.fft_y_chunk(z, N, nx, G, C_, c)) for z in comps]
-                            for c in range(C_)])
+        self.prepare()
+        with self._bin_scope():
+            for i in range(0, len(zimgs), group):
+                comps = zimgs[i:i + group]
+                started.append([[self.comm.all_to_all_start(k.fft_y_chunk(z, N, nx, G, C_, c)) for z in comps]
+                                for c in range(C_)])
         return started
 
     def finish_zimages(self, started, psum=None, nsample=None, count=True):
@@ -738,9 +780,10 @@ class PowerPipeline:
         nky = N // G           # Nyquist-plane ky rows per rank
         # one rank: no exchange -- z/y passes of every field, then the x passes
         pending = []
-        for f in fields:
-            spec, nyq = k.fft_zy(f, N, nx) if weight is None else k.fft_zy(f, N, nx, weight=weight)
-            pending.append((self.comm.all_to_all_start(spec), self.comm.all_to_all_start(nyq)))
+        with self._bin_scope():
+            for f in fields:
+                spec, nyq = k.fft_zy(f, N, nx) if weight is None else k.fft_zy(f, N, nx, weight=weight)
+                pending.append((self.comm.all_to_all_start(spec), self.comm.all_to_all_start(nyq)))
         self._bin_exchanged(pending, psum, nsample, count)
         return psum, nsample
 

@@ -305,8 +305,10 @@ class BoxField:
         if src is not None and k.fused_supported(self.Nsize, _dev.QUANTITY[quantity]):
             # particle-backed field: particles -> z/y-transformed spectra in one go (no grid in HBM)
             flags = _dev.FLAG_REFERENCE_MOMENTUM_BUG if (quantity == "momentum" and REFERENCE_COMPAT["momentum_bug"]) else 0
-            spec, nyq = k.deposit_fft_zy(src[0], src[1], src[2], self.Nsize, self.Lbox, 0, self.Nsize,
-                                         _dev.QUANTITY[quantity], flags, reuse_sort=getattr(self, "_sort_token", None))
+            pipe.prepare()
+            with k.binning_only():      # the spectra go straight into the binning pass
+                spec, nyq = k.deposit_fft_zy(src[0], src[1], src[2], self.Nsize, self.Lbox, 0, self.Nsize,
+                                             _dev.QUANTITY[quantity], flags, reuse_sort=getattr(self, "_sort_token", None))
             self._sort_token = k.fused_token()       # a second quantity of this field skips the particle sort
             tab = pipe.finish(*pipe.accumulate_spectra(spec, nyq))
             tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2
