@@ -567,3 +567,44 @@ def test_higher_order_assignment_and_deconvolution(K, assignment):
     finally:
         del os.environ["VPS_NO_FAST_BINNING"]
     assert np.array_equal(sp3.Nsample, r1[:, 3]) and np.allclose(sp3.Psum, r1[:, 2], rtol=PSUM_RTOL, atol=0)
+
+
+# ------------------------------------------------- rows nobody bins are not moved ----
+@pytest.mark.parametrize("N", [128, 256, 250])
+def test_binning_only_scope_skips_exactly_the_unbinned_rows(K, N):
+    """Inside a `binning_only` scope the y passes leave every row (ky, kz) with fl(ky^2 + kz^2) >= thr[nbins] untouched
+    (all its modes lie beyond the last edge np.histogram keeps) and write every other row as before; the binning x pass
+    gives bit-identical counts and the same sums with or without the scope; rfft3 / power_grid are not affected by it."""
+    from vpower import device
+    rng = np.random.default_rng(N)
+    f = K.to_device(rng.standard_normal((N, N, N)).astype(np.float32))
+    pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=device.SlabComm(enabled=False))
+    pipe.prepare()
+    full_s, full_n = K.fft_zy(f, N, N)
+    sentinel = complex(1234.5, -6789.0)
+    spec = torch.full_like(full_s, sentinel)
+    nyq = torch.full_like(full_n, sentinel)
+    with K.binning_only():
+        K.fft_zy(f, N, N, spec=spec, nyq=nyq)
+        ref3 = K.rfft3(f, N)                     # asks for every mode: must ignore the scope
+    k2, thr_last = pipe.k2, pipe.thr[-1]
+    beyond = (k2[None, : N] + k2[: N // 2 + 1, None]) >= thr_last                # [kz <= N/2][ky]
+    kept = ~beyond
+    got = torch.cat([spec, nyq[None]], dim=0)                                      # [kz <= N/2][ky][x]
+    want = torch.cat([full_s, full_n[None]], dim=0)
+    untouched = (got == sentinel).all(dim=2).cpu().numpy()
+    written = (got == want).all(dim=2).cpu().numpy()
+    assert written[kept].all()                       # every row that can reach a shell is there, bit for bit
+    assert (untouched | written).all()               # a row is either written in full or not at all
+    assert not untouched[kept].any()
+    if N % 2 == 0 and N >= 128 and (N & (N - 1)) == 0:
+        assert untouched[beyond].mean() > 0.6        # most of the corner rows were skipped (16-row rounding keeps a few)
+    assert torch.equal(ref3, K.rfft3(f, N))
+    # shell sums: identical counts, sums equal to rounding of the summation order
+    a = pipe.finish(*pipe.accumulate([f]))
+    K.set_binning(*pipe._binning)
+    ps, ns = K.zeros((pipe.nbins,), torch.float64), K.zeros((pipe.nbins,), torch.int64)
+    K.fft_x_bin(full_s, N, (N // 2) * N, 0, 0, 1, 0, ps, ns)
+    K.fft_x_bin(full_n, N, N, 0, N // 2, 1, 0, ps, ns)
+    b = pipe.finish(ps, ns)
+    assert np.array_equal(a[:, 3], b[:, 3]) and np.allclose(a[:, 2], b[:, 2], rtol=1e-12, atol=0)
