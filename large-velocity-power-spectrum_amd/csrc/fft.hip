@@ -557,7 +557,8 @@ __device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf*
 // One workgroup transforms T lines a0..a0+T-1 of batch b and writes, for every
 // output index k, the T results to T contiguous complex slots out[b][k][a0..].
 // ------------------------------------------------------------------------------
-// NTEMP: non-temporal loads and stores (y pass of images up to ~0.75 GB: -4..-9 % there, +2..+5 % on larger ones)
+// NTEMP: non-temporal loads and stores (y pass of images up to ~0.75 GB: -4..-9 % there; on larger ones +2..+5 % with
+// 64-byte segments, -6 % with full 128-byte lines)
 // KG: the Nyquist-plane launch of the chunked exchange (output rows shifted per destination rank, PassParams::kg) -- its own
 // instantiation, so that the main passes carry no per-element division
 template <int NC, int T, bool REAL, bool NTEMP = false, bool KG = false>
@@ -664,6 +665,116 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
   } else {
     cf* nyq = reinterpret_cast<cf*>(p.out_nyq) + (long long)b * p.nyq_ob + a0;
     r2c_store_tile<NC, T, NT, true>(buf, tid, p.tw_r2c, out, p.out_ok, nyq, p.A - a0);
+  }
+}
+
+
+// ------------------------------------------------------------------------------
+// Wide transposing y pass for lines whose 16-line tile does not fit LDS (NC > 1024).
+// What bounds the transposing pass of long lines is the WRITE pattern, not the transform: a plain
+// transposing copy of a 2048^3 half spectrum (tools/micro/transpose_bw.hip) moves 3.9 TB/s with the
+// 64-byte segments of 8-line tiles and 5.5 TB/s with full 128-byte lines -- and fft_transpose_pass<2048, 8>
+// ran at exactly the former.  This kernel writes 128-byte segments with the LDS of an 8-line tile:
+// a workgroup loads 2 x TG lines, transforms them one TG-line group after the other through the same
+// exchange buffers (the first group's spectrum waits in registers), and then stages the transposed
+// image in two k-halves [NC/2][2 TG] -- after the last radix-R stage register slot (m, r) holds
+// k = l + L m + r NC/R, so r < R/2 is exactly the lower half.
+// ------------------------------------------------------------------------------
+template <int NC, int TG, int L, bool NTEMP, bool KG>
+__global__ void __launch_bounds__(TG* L)
+    fft_transpose_pass_wide(const PassParams p) {
+  typedef PlanInfo<NC> PI;
+  constexpr int RL = NC / L, NT = TG * L, T = 2 * TG;
+  constexpr int R = LastRadix<NC>::R;
+  static_assert((R & 1) == 0 && (NC & 1) == 0, "the image is staged in two k-halves");
+  static_assert(((NC / 2) * T) % NT == 0, "whole store rounds");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cf* tw_lds = reinterpret_cast<cf*>(smem_raw);
+  cf* buf = tw_lds + PI::TWL;
+  const cf* tw = PI::TWLDS ? tw_lds : p.tw_stage;
+
+  const int tid = threadIdx.x;
+  const int t = tid / L, l = tid % L;
+  const int tiles = (p.A + T - 1) / T;
+  const unsigned bid = blockIdx.x;
+  const int bo = bid / tiles;                 // batch as the output sees it
+  const int a0 = (bid % tiles) * T;
+  const long long b = p.bg ? (long long)(bo / p.bg) * p.bg_in + p.b_off + bo % p.bg : bo;   // batch as the input sees it
+  const long long ogap = p.bg ? (long long)(bo / p.bg) * p.bg_gap : 0;
+
+  if constexpr (PI::TWLDS)
+    for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
+
+  // stage-0 inputs of line a0 + line of a thread `who` (the thread index, possibly laundered -- see below)
+  auto load_line = [&](cf (&v)[RL], int who, int first) {
+    constexpr int R0 = PI::R0, NB = RL / R0;
+    const int tl = who / L, ll = who % L;
+    const bool live = (a0 + first + tl) < p.A;
+    const cf* src = reinterpret_cast<const cf*>(p.in) + (long long)b * p.in_sb + (long long)(a0 + first + tl) * p.in_sa;
+#pragma unroll
+    for (int m = 0; m < NB; ++m)
+#pragma unroll
+      for (int r = 0; r < R0; ++r) {
+        const int j = ll + L * m + r * (NC / R0);
+        if constexpr (NTEMP) {
+          v[m * R0 + r] = live ? load_stream(&src[j]) : make_float2(0.f, 0.f);
+        } else {
+          v[m * R0 + r] = live ? src[j] : make_float2(0.f, 0.f);
+        }
+      }
+  };
+  // Register budget: 1024 threads leave 128 VGPRs, and two groups' values are 64 of them.  Left to itself the compiler
+  // forms the LDS / global addresses of BOTH transforms and of the store loops once, ahead of the first transform, and
+  // keeps ~40 of them live throughout (84 bytes per lane spilled, +4 % run time).  A thread index passed through an
+  // empty asm is a new value to it: addresses derived from it are formed where they are used.
+  auto fresh = [](int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+  };
+  cf v0[RL], v1[RL];
+  load_line(v0, tid, 0);
+  __syncthreads();  // twiddle image visible
+  constexpr bool WSYNC = (L <= 64) && (64 % L == 0);
+  fft_from_regs_l<NC, L, WSYNC>(v0, buf + t * PI::PITCH, tw, l);
+  // (requesting the second group ahead of the first transform measured 14.1 against 13.6 ms per 2048^3 launch; from
+  // inside it, before its last butterflies, 13.55)
+  load_line(v1, fresh(tid), TG);
+  __syncthreads();  // every lane done with the per-line buffers
+  {
+    const int tidb = fresh(tid);
+    fft_from_regs_l<NC, L, WSYNC>(v1, buf + (tidb / L) * PI::PITCH, tw, tidb % L);
+  }
+
+  cf* out = reinterpret_cast<cf*>(p.out) + (long long)bo * p.out_ob + ogap + a0;
+  const int kc = p.kcut ? p.kcut[p.kz_fixed >= 0 ? p.kz_fixed : (int)b] : NC;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();  // exchange buffers / the previous half image are free
+    const int tid2 = fresh(tid);
+#pragma unroll
+    for (int i = 0; i < RL; ++i) {
+      if (((i % R) >= R / 2) == (h == 1)) {
+        const int k = out_index_l<NC, L>(tid2 % L, i) - h * (NC / 2);
+        buf[tridx<T>(k, tid2 / L)] = v0[i];
+        buf[tridx<T>(k, tid2 / L + TG)] = v1[i];
+      }
+    }
+    __syncthreads();
+    constexpr int IT = (NC / 2) * T / NT;
+#pragma unroll 4
+    for (int i = 0; i < IT; ++i) {
+      const int idx = tid2 + i * NT;
+      const int tt = idx % T, kk = idx / T, k = kk + h * (NC / 2);
+      if (a0 + tt < p.A && min(k, NC - k) <= kc) {
+        const cf val = buf[tridx<T>(kk, tt)];
+        long long o = (long long)k * p.out_ok + tt;
+        if constexpr (KG) o += (long long)(k / p.kg) * p.kg_gap;
+        if constexpr (NTEMP)
+          store_stream(&out[o], val);
+        else
+          out[o] = val;
+      }
+    }
   }
 }
 
@@ -1320,6 +1431,16 @@ constexpr int xpass_T() {
   return (t > 1 && (t & 1)) ? t - 1 : t;   // even, so that a tile holds whole (ky, N-ky) pairs (L = 50 -> 4)
 }
 
+// lines whose y pass runs the wide kernel (two 8-line groups per workgroup)
+template <int NC>
+constexpr bool wide_transpose() {
+#ifdef VPS_Y_NO_WIDE
+  return false;
+#else
+  return NC == 1536 || NC == 2048 || NC == 4096;   // (2000: 800 threads x 2 x 20 points do not fit 128 VGPRs)
+#endif
+}
+
 template <int NC, int T>
 size_t transpose_lds_bytes() {
   typedef PlanInfo<NC> PI;
@@ -1340,13 +1461,37 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
   // still 124 bytes per lane of scratch and 164 ms per step of y passes against 113 ms for this kernel.  This kernel itself
   // on half the lanes (512 threads, 197 VGPRs, no spill, wave-level exchanges): 121.5 against 115.6 ms.  The persistent
   // form at the plan's 1024 threads with the lane indices re-materialised per tile (117 VGPRs, no spill): 137.9 ms.  Not kept.)
-  constexpr int T = (NC == 1024 && !REAL) ? 16 : transpose_T<NC>();
   typedef PlanInfo<NC> PI;
+  constexpr int T = (NC == 1024 && !REAL) ? 16 : transpose_T<NC>();
+  if constexpr (!REAL && wide_transpose<NC>()) {
+    // 2 x T lines per workgroup, 128-byte output segments (fft_transpose_pass_wide)
+    const size_t lds = transpose_lds_bytes<NC, T>();
+    // full 128-byte lines written once: non-temporal stores (2048^3: 3.93 against 4.56 ms per 512-row slab; with the 64-byte
+    // segments of the 8-line kernel they were a loss on images this large).  On half the plan's lanes per line (512 threads)
+    // the kernel spills 47 registers.
+    constexpr int LW = PI::L;
+    auto kern = fft_transpose_pass_wide<NC, T, LW, true, false>;
+    if (p.kg) kern = fft_transpose_pass_wide<NC, T, LW, true, true>;
+    if (lds > 64 * 1024)
+      VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long tiles = (p.A + 2 * T - 1) / (2 * T);
+    const long long grid = tiles * p.B;
+    if (grid <= 0 || grid > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_ARG, "fft grid out of range");
+    {
+      vps_launch_timer tm(ctx, kind);
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(T * LW), lds, ctx->stream, p);
+    }
+    VPS_HIP_CHECK(ctx, hipGetLastError());
+    return VPS_OK;
+  }
   const size_t lds = transpose_lds_bytes<NC, T>();
   auto kern = fft_transpose_pass<NC, T, REAL>;
   if constexpr (!REAL) {
     const double image_bytes = 8.0 * (double)p.A * (double)p.B * (double)NC;
-    if (image_bytes <= 768.0 * 1048576.0) kern = fft_transpose_pass<NC, T, REAL, true>;
+    // non-temporal loads and stores: always with full 128-byte segments (T >= 16: 1024^3 y pass 1.79 against 1.90 ms);
+    // with narrower tiles only while the image is small (partial lines have to meet in L2 first)
+    if (image_bytes <= 768.0 * 1048576.0 || T >= 16) kern = fft_transpose_pass<NC, T, REAL, true>;
     if (p.kg) kern = fft_transpose_pass<NC, T, REAL, true, true>;   // Nyquist plane of a chunked exchange (one small image)
   }
   if (lds > 64 * 1024)
