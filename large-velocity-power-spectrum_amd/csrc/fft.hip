@@ -526,8 +526,13 @@ __device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf*
     const int idx = tid + i * NT;
     if ((PAIRS % NT) != 0 && idx >= PAIRS) break;
     const int tt = idx % T, k = idx / T;
+#ifdef VPS_PENCIL_NOSTORE
+    const cf zk = buf[tridx<T>(k, tt)];
+    const bool ok = (!BOUNDS || tt < nlive) && (zk.x == 1.2345e30f);   // TIMING ONLY: nothing is stored
+#else
     const bool ok = !BOUNDS || tt < nlive;
     const cf zk = buf[tridx<T>(k, tt)];
+#endif
     if (k == 0) {
       if (ok) {
         out[tt] = make_float2(zk.x + zk.y, 0.f);
@@ -545,8 +550,19 @@ __device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf*
       const cf wd = cmul(w, d);
       if (ok) {
         // -i * wd = (wd.y, -wd.x);  for NC-k: conj(sm) and -i * conj(wd) = (-wd.y, -wd.x)
+#ifdef VPS_PENCIL_FAKE128
+        if (T == 8 && !BOUNDS) {   // TIMING ONLY (wrong addresses): the same stores as 128-byte segments
+          const int par = (int)((reinterpret_cast<unsigned long long>(out) >> 6) & 1);
+          cf* o16 = out - 8 * par;
+          const int k2 = NC - k;
+          store_stream(&o16[(long long)((k & ~1) + par) * out_ok + tt + 8 * (k & 1)], make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x)));
+          store_stream(&o16[(long long)((k2 & ~1) + par) * out_ok + tt + 8 * (k2 & 1)], make_float2(0.5f * (sm.x - wd.y), 0.5f * (-sm.y - wd.x)));
+        } else
+#endif
+        {
         store_stream(&out[(long long)k * out_ok + tt], make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x)));
         store_stream(&out[(long long)(NC - k) * out_ok + tt], make_float2(0.5f * (sm.x - wd.y), 0.5f * (-sm.y - wd.x)));
+        }
       }
     }
   }
@@ -798,37 +814,34 @@ struct PencilParams {
   int divide;                // 1: v = q / rho (0 where rho == 0);  0: p = q * vol
   int energy;                // 1: ONE output field E = vol * sum_c q_c^2 / rho (= mass * |v|^2, interp.py:546)
   float vol;
+  float* side;               // [records] one float per record, for the records a workgroup cannot keep in registers
   cf* out[3];                // B_c[x][kz][y]
   cf* nyq[3];                // BN_c[x][y]
   const cf* tw_stage;
   const cf* tw_r2c;
 };
 
-// tuning knob (measured at 512^3 / 1024^3): 4 waves/SIMD needs <= 128 VGPRs
+// tuning knobs (measured at 512^3 / 1024^3 / 2048^3): 4 waves/SIMD needs <= 128 VGPRs
 #ifndef VPS_PENCIL_MINW
 #define VPS_PENCIL_MINW 4
 #endif
-
-// 2048-cell lines (NC = 1024): 16 transform registers + 16 scale factors per lane (+ 16 energy sums) do not fit the 128
-// VGPRs that four waves per SIMD allow -- the kernel spilled 88 (292: energy) bytes per lane to scratch, and the scratch
-// traffic (PMC: 141 GB written per velocity launch against 103 GB of output, 158 GB against 34 GB for energy) was what
-// the launch waited for.  Two waves per SIMD (one 8-line workgroup per CU) keep everything in registers.
 #ifndef VPS_PENCIL_MINW_LONG
-#define VPS_PENCIL_MINW_LONG 2
+#define VPS_PENCIL_MINW_LONG 4
 #endif
 template <int NC>
 constexpr int pencil_min_waves() {
   return NC >= 1024 ? VPS_PENCIL_MINW_LONG : VPS_PENCIL_MINW;
 }
 
-// Lanes per line: the plan's, except for 2048-cell lines, where a line runs on HALF of them (32 lanes x 32 points): 16
-// lines -- full 128-byte output segments -- are then 512 threads instead of 1024, two waves per SIMD with a 256-VGPR
-// budget instead of four with 128 (which this kernel spills at: 88 / 292 bytes per lane).  8-line pencils on the plan's
-// lanes avoid the spills too, but their 64-byte segments only merged for 62 % of the lines even with the partner pencils
-// placed on one XCD (PMC WRITE_SIZE 142 GB for 103 GB of output at 2048^3).
+// Lanes per line: the plan's.  (While the kernel kept 1/rho -- and for energy the sums of squares -- per CELL in
+// registers, 2048-cell lines did not fit the 128 VGPRs of four waves per SIMD: it ran them on half the lanes, two waves
+// per SIMD, 83 ms per C4 step of which 65 ms were on-chip work that nothing overlapped.)
+#ifndef VPS_PENCIL_HALF_LANES_LONG
+#define VPS_PENCIL_HALF_LANES_LONG 0
+#endif
 template <int NC>
 constexpr int pencil_lanes() {
-  return NC >= 1024 ? PlanInfo<NC>::L / 2 : PlanInfo<NC>::L;
+  return (NC >= 1024 && VPS_PENCIL_HALF_LANES_LONG) ? PlanInfo<NC>::L / 2 : PlanInfo<NC>::L;
 }
 
 template <int NC, int TP, bool ENERGY = false>
@@ -840,12 +853,16 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
   constexpr int SHARED = (ACC > LINES ? ACC : LINES);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // ONE LDS region serves, in turn, as the rho accumulator, each rho*v accumulator and the FFT's
-  // exchange / transposed-image buffer; 1/rho of the cells a thread feeds into stage 0 lives in
-  // its registers (the cells are the same for every component).
+  // exchange / transposed-image buffer.
   float* acc = reinterpret_cast<float*>(smem_raw);
   cf* buf = reinterpret_cast<cf*>(acc);
   cf* tw_lds = reinterpret_cast<cf*>(acc + SHARED);
-  const cf* tw = PI::TWLDS ? tw_lds : p.tw_stage;
+#ifdef VPS_PENCIL_TW_GLOBAL
+  constexpr bool TWL = false;
+#else
+  constexpr bool TWL = PI::TWLDS;
+#endif
+  const cf* tw = TWL ? tw_lds : p.tw_stage;
 
   const int tid = threadIdx.x;
   const int t = tid / L, l = tid % L;
@@ -865,16 +882,21 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
   const unsigned s = p.start[pencil], e = p.start[pencil + 1];
   // more than two particles per cell on average: hot cells are likely, take the native atomics (vps_lds_add)
   const bool crowded = (e - s) > 2u * (unsigned)ACC;
-  if constexpr (PI::TWLDS)
+  if constexpr (TWL)
     for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
-  // The cells of the first KR*NT records of the bucket stay in registers; the value each round adds
-  // (rho, then rho v_c) is fetched one round ahead, so the loads fly behind the previous round's FFT.
-  // Only unusually full pencils read records inside a round (tail loops below).
+  // What a CELL needs besides the sums -- 1/rho (velocity), the running sum of (rho v_c)^2 (energy) -- is kept per RECORD:
+  // every record of a cell reads the cell's total from the accumulator and carries the same value.  A per-cell table would
+  // be RL register pairs per lane next to the RL transform registers (it was: the kernel then fit four waves per SIMD only
+  // up to 1024-cell lines, and not at all for energy); per record it is KR registers, whatever the line length.
+  // The cells of the first KR*NT records of the bucket stay in registers; the value each round adds (rho, then rho v_c) is
+  // fetched one round ahead, so the loads fly behind the previous round's FFT.  Only unusually full pencils read records
+  // inside a round (tail loops below); their per-record value lives in p.side[record].
   // register-resident record groups: enough for a typical bucket (~1.2 x mean occupancy at the bench
   // densities) -- 3 x 256 threads at 512^3, 2 x 512 at 1024^3 (measured optimum each)
   constexpr int KR = NT >= 512 ? 2 : (NT >= 256 ? 3 : 4);
   unsigned rloc[KR];
   float rval[KR];
+  float rrec[KR];   // 1/rho of the record's cell (velocity) / sum over components of (rho v_c)^2 of its cell (ENERGY)
   auto fetch = [&](int word) {   // record word 1..3: rho v_c, 4: rho
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
@@ -886,93 +908,125 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
   for (int k = 0; k < KR; ++k) {
     const unsigned j = s + tid + k * NT;
     rloc[k] = (j < e) ? p.records[(size_t)j * 5] : 0xffffffffu;
+    rrec[k] = 1.f;
   }
-  fetch((p.divide && !ENERGY) ? 4 : 1 + p.chan[0]);
+  const bool divide = !ENERGY && p.divide;
+  fetch(divide ? 4 : 1 + p.chan[0]);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int R0 = PI::R0, NB0 = RL / R0;
-  float2 scale[RL];   // per stage-0 input cell pair: 1/rho (0 where empty) or Lcell^3 (ENERGY: unused -- rho comes last)
-  if (!ENERGY && p.divide) {
+  const unsigned tail0 = s + tid + KR * NT;   // this thread's first record beyond the register-resident ones
+  if (divide) {
     for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KR; ++k)
       if (rloc[k] != 0xffffffffu) vps_lds_add(&acc[rloc[k]], rval[k], crowded);
     fetch(1 + p.chan[0]);
-    for (unsigned j = s + tid + KR * NT; j < e; j += NT) {
+    for (unsigned j = tail0; j < e; j += NT) {
       const unsigned* rec = p.records + (size_t)j * 5;
       vps_lds_add(&acc[rec[0]], __uint_as_float(rec[4]), crowded);
     }
     __syncthreads();
-    const float* r = acc + t * N;
+    // one reciprocal per record; empty-rho cells give 0 (the NaN->0 rule of interp.py:329-331)
 #pragma unroll
-    for (int m = 0; m < NB0; ++m)
-#pragma unroll
-      for (int rr = 0; rr < R0; ++rr) {
-        const int j = l + L * m + rr * (NC / R0);
-        const float2 dd = *reinterpret_cast<const float2*>(r + 2 * j);
-        // one reciprocal per cell; empty cells give 0 (the NaN->0 rule of interp.py:329-331)
-        scale[m * R0 + rr] = make_float2(dd.x != 0.f ? __builtin_amdgcn_rcpf(dd.x) : 0.f,
-                                         dd.y != 0.f ? __builtin_amdgcn_rcpf(dd.y) : 0.f);
+    for (int k = 0; k < KR; ++k)
+      if (rloc[k] != 0xffffffffu) {
+        const float r = acc[rloc[k]];
+        rrec[k] = r != 0.f ? __builtin_amdgcn_rcpf(r) : 0.f;
       }
-  } else {
-#pragma unroll
-    for (int i = 0; i < RL; ++i) scale[i] = make_float2(p.vol, p.vol);
+    for (unsigned j = tail0; j < e; j += NT) {
+      const float r = acc[p.records[(size_t)j * 5]];
+      p.side[j] = r != 0.f ? __builtin_amdgcn_rcpf(r) : 0.f;
+    }
   }
 
-  cf e2[ENERGY ? RL : 1];   // sum over the components of (rho v_c)^2 per stage-0 cell (ENERGY only)
-  // ENERGY: the three rho*v_c rounds add up q_c^2, a FOURTH round accumulates rho and finishes E = vol * sum / rho -- so that
-  // the 1/rho table never has to live through the component rounds next to the sums (registers)
+  // ENERGY: the three rho*v_c rounds add up q_c^2 per record, a FOURTH round accumulates rho and finishes
+  // E = vol * sum / rho in the cells that hold records (all others stay 0)
   const int nround = ENERGY ? p.ncomp + 1 : p.ncomp;
   for (int c = 0; c < nround; ++c) {
     // opaque copies: keeps the compiler from hoisting ~50 loop-invariant LDS addresses out of the
-    // component loop (they cost more registers than the 1/rho table and an occupancy step)
+    // component loop (they cost more registers than they save instructions, and an occupancy step)
     int lc = l, tc = t, tidc = tid;
     asm volatile("" : "+v"(lc), "+v"(tc), "+v"(tidc));
     lc &= L - 1;   // give the value ranges back to the compiler (address folding needs them)
     tc &= TP - 1;
     tidc &= NT - 1;
     __syncthreads();   // rho / previous component's transposed image fully consumed
+#ifndef VPS_ABL_NOZERO
     for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
+#endif
     __syncthreads();
-    const int word = (ENERGY && c == p.ncomp) ? 4 : 1 + p.chan[c < p.ncomp ? c : 0];
+    const bool rho_round = ENERGY && c == p.ncomp;
+    const int word = rho_round ? 4 : 1 + p.chan[c < p.ncomp ? c : 0];
+    // velocity: each term is divided by its cell's rho as it is added -- sum_k (q_k / rho) for the reference's
+    // (sum_k q_k) / rho: a different rounding of the same value, within the float32 accumulation noise of the sums
+#ifndef VPS_ABL_NOSCATTER
 #pragma unroll
     for (int k = 0; k < KR; ++k)
-      if (rloc[k] != 0xffffffffu) vps_lds_add(&acc[rloc[k]], rval[k], crowded);
+      if (rloc[k] != 0xffffffffu) vps_lds_add(&acc[rloc[k]], divide ? rval[k] * rrec[k] : rval[k], crowded);
+#endif
     if (c + 1 < nround) fetch((ENERGY && c + 1 == p.ncomp) ? 4 : 1 + p.chan[c + 1 < p.ncomp ? c + 1 : 0]);
-    for (unsigned j = s + tid + KR * NT; j < e; j += NT) {
+    for (unsigned j = tail0; j < e; j += NT) {
       const unsigned* rec = p.records + (size_t)j * 5;
-      vps_lds_add(&acc[rec[0]], __uint_as_float(rec[word]), crowded);
+      const float val = __uint_as_float(rec[word]);
+      vps_lds_add(&acc[rec[0]], divide ? val * p.side[j] : val, crowded);
     }
     __syncthreads();
+    if constexpr (ENERGY) {
+      if (!rho_round) {
+        // the cell totals of this component, squared, per record
+#pragma unroll
+        for (int k = 0; k < KR; ++k)
+          if (rloc[k] != 0xffffffffu) {
+            const float q = acc[rloc[k]];
+            rrec[k] = (c == 0) ? q * q : rrec[k] + q * q;
+          }
+        for (unsigned j = tail0; j < e; j += NT) {
+          const float q = acc[p.records[(size_t)j * 5]];
+          p.side[j] = (c == 0) ? q * q : p.side[j] + q * q;
+        }
+        continue;   // (the barrier at the top of the loop protects the accumulator)
+      }
+      // the accumulator holds rho: E = sum * (1 / rho) * vol where there is mass, 0 elsewhere -- every record writes its cell's
+      // value (records of one cell write the same bits), after everybody has read rho
+#pragma unroll
+      for (int k = 0; k < KR; ++k)
+        if (rloc[k] != 0xffffffffu) {
+          const float r = acc[rloc[k]];
+          rrec[k] = r != 0.f ? rrec[k] * __builtin_amdgcn_rcpf(r) * p.vol : 0.f;
+        }
+      for (unsigned j = tail0; j < e; j += NT) {
+        const float r = acc[p.records[(size_t)j * 5]];
+        p.side[j] = r != 0.f ? p.side[j] * __builtin_amdgcn_rcpf(r) * p.vol : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < KR; ++k)
+        if (rloc[k] != 0xffffffffu) acc[rloc[k]] = rrec[k];
+      for (unsigned j = tail0; j < e; j += NT) acc[p.records[(size_t)j * 5]] = p.side[j];
+      __syncthreads();
+    }
     // stage-0 inputs straight from the accumulator: z[j] = f[2j] + i f[2j+1]
     cf v[RL];
     {
       const float* q = acc + tc * N;
+      const float sc = (ENERGY || divide) ? 1.f : p.vol;
 #pragma unroll
       for (int m = 0; m < NB0; ++m)
 #pragma unroll
         for (int rr = 0; rr < R0; ++rr) {
           const int j = lc + L * m + rr * (NC / R0);
           const float2 qq = *reinterpret_cast<const float2*>(q + 2 * j);
-          if constexpr (ENERGY) {
-            cf& a2 = e2[m * R0 + rr];
-            if (c < p.ncomp) {
-              a2 = (c == 0) ? make_float2(qq.x * qq.x, qq.y * qq.y) : make_float2(a2.x + qq.x * qq.x, a2.y + qq.y * qq.y);
-            } else {   // qq = rho of the two cells; empty cells give 0 (the NaN->0 rule of interp.py:329-331)
-              v[m * R0 + rr] = make_float2(qq.x != 0.f ? a2.x * __builtin_amdgcn_rcpf(qq.x) * p.vol : 0.f,
-                                           qq.y != 0.f ? a2.y * __builtin_amdgcn_rcpf(qq.y) * p.vol : 0.f);
-            }
-          } else {
-            const float2 sc = scale[m * R0 + rr];
-            v[m * R0 + rr] = make_float2(qq.x * sc.x, qq.y * sc.y);
-          }
+          v[m * R0 + rr] = make_float2(qq.x * sc, qq.y * sc);
         }
-    }
-    if constexpr (ENERGY) {
-      if (c + 1 < nround) continue;   // (the barrier at the top of the loop protects the accumulator)
     }
     __syncthreads();   // accumulator of this component consumed: its memory becomes FFT scratch
     constexpr bool WSYNC = (L <= 64) && (64 % L == 0);
+#ifdef VPS_ABL_NOFFT
+#pragma unroll
+    for (int i = 0; i < RL; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y));
+    if (v[0].x != 1.2345e30f) continue;
+#endif
     fft_from_regs_l<NC, L, WSYNC>(v, buf + tc * PI::PITCH, tw, lc);
     __syncthreads();
 #pragma unroll
@@ -1961,7 +2015,7 @@ bool vps_pencil_supported(vps_ctx* ctx, int N) {
 
 // records sorted by pencil -> ncomp half spectra after the z and y passes (spec_dev == NULL: z pass only, the
 // z images [component][B | BN] stay in bwork_dev)
-int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, const unsigned* start,
+int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, const unsigned* start, float* side,
                       int ncomp, const int* chan, int divide, int energy, float vol, void* spec_dev, void* nyq_dev,
                       void* bwork_dev) {
   const int NH = N / 2;
@@ -1973,6 +2027,7 @@ int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, cons
   PencilParams p{};
   p.records = records;
   p.start = start;
+  p.side = side;
   p.N = N;
   p.nx = nx;
   p.nby = N / vps_pencil_tp(N);

@@ -104,7 +104,8 @@ void vps_fft_free_tables(vps_ctx* ctx);
 // fused deposit -> z pass ("pencil" path): records sorted by pencil -> ncomp half spectra
 int vps_pencil_tp(int N);
 bool vps_pencil_supported(vps_ctx* ctx, int N);
-int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, const unsigned* start,
+// side: one float per record (scratch of the kernel: what it keeps per record when a bucket outgrows its registers)
+int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, const unsigned* start, float* side,
                       int ncomp, const int* chan, int divide, int energy, float vol, void* spec_dev, void* nyq_dev,
                       void* bwork_dev);
 
