@@ -1357,14 +1357,20 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
               if (partner_cur) pv += mirr[POFF + 1];
               c = 2u;
             }
+#ifdef VPS_ABL_X_NOATOMIC
+            if ((unsigned)bin < (unsigned)p.nbins && pv == 1.2345e30f) {   // TIMING ONLY
+#else
             if ((unsigned)bin < (unsigned)p.nbins) {
+#endif
               if (p.win) pv *= wl[l * H + i];
               atomicAdd(&hsum[bin], (double)(pv * wf));
               if constexpr (COUNT) atomicAdd(&hcnt[bin], c * w);
             }
           };
+#ifndef VPS_ABL_X_NOBIN
 #pragma unroll
           for (int i = 0; i < H; ++i) bin_one(i, k2x[i]);
+#endif
           if (l == L - 1) {   // the unpaired kx = NC/2 mode
             const double s = (k2half + k2y_cur) + k2z_cur;
             int g = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);

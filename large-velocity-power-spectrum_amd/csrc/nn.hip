@@ -439,6 +439,13 @@ __global__ void __launch_bounds__(256)
 //     visited it (the R-box of a particle covers its R-ball).
 // Unresolved or contested points (voids, near-ties, duplicates: 2e-3 of the points at C3 with kappa = 1.15) are
 // appended to a list and finished by nn_fallback_kernel with the exact float64 ring search.
+//
+// (Measured alternative, not kept: a point-centric "gather" form inside this kernel for sparse tiles -- region particles
+// staged in LDS, every wave collecting the particles inside the R-box of a 4x4x4 block of points through the staged cell
+// columns and evaluating them for its 64 points in registers, two candidates per packed instruction, no atomics: 35 ms at
+// C3 against 33.5 ms for the scatter -- 17 ms in the ~45 evaluations per point, 8.6 ms collecting the candidates, 9.4 ms
+// in what both forms share (region set-up, 17 GB of output) -- and its 28 KB of LDS cost the scatter form a workgroup
+// per CU.)
 // ------------------------------------------------------------------------------------------------
 constexpr int NT_T = 16;                  // lattice tile edge
 constexpr int NT_PTS = NT_T * NT_T * NT_T;
