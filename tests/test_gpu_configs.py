@@ -473,14 +473,20 @@ def test_nn_scatter_and_query_centric_kernels_agree(K, monkeypatch):
 
 
 # --------------------------------------------------- chunked exchange layout (one GPU) ----
-@pytest.mark.parametrize("N,G,C", [(64, 2, 1), (128, 4, 2), (128, 4, 4), (256, 8, 2), (500, 5, 2), (250, 5, 1)])
+@pytest.mark.parametrize("N,G,C", [(64, 2, 1), (128, 4, 2), (128, 4, 4), (256, 8, 2), (500, 5, 2), (250, 5, 1),
+                                   (1536, 8, 2), (2048, 8, 4)])   # the last two: the wide y pass (16 lines per workgroup), C4's 8-rank layout
 def test_chunked_y_pass_layout_emulated_ranks(K, N, G, C):
     """vps_fft_z + vps_fft_y with the real kernels: every emulated rank produces its send buffers chunk by chunk, the
     all-to-all is played by slicing them, the x pass reads the received blocks (Nyquist rows behind the last chunk) --
     the result must equal the one-rank transform of the same field."""
     from vpower import device
-    rng = np.random.default_rng(N + G + C)
-    f = K.to_device(rng.standard_normal((N, N, N)).astype(np.float32))
+    if N >= 1024:   # generated on the device: a host array of this size would take minutes
+        gen = torch.Generator(device=K.device)
+        gen.manual_seed(N + G + C)
+        f = torch.randn((N, N, N), dtype=torch.float32, device=K.device, generator=gen)
+    else:
+        rng = np.random.default_rng(N + G + C)
+        f = K.to_device(rng.standard_normal((N, N, N)).astype(np.float32))
     pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=device.SlabComm(enabled=False))
     ref = pipe.finish(*pipe.accumulate([f]))
     nx, nkz, nky = N // G, N // 2 // G, N // G
