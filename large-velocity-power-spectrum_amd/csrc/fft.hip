@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
 // image in two k-halves [NC/2][2 TG] -- after the last radix-R stage register slot (m, r) holds
 // k = l + L m + r NC/R, so r < R/2 is exactly the lower half.
 // ------------------------------------------------------------------------------
-template <int NC, int TG, int L, bool NTEMP, bool KG>
+template <int NC, int TG, int L, bool NTEMP>
 __global__ void __launch_bounds__(TG* L)
     fft_transpose_pass_wide(const PassParams p) {
   typedef PlanInfo<NC> PI;
@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(TG* L)
 #pragma unroll
       for (int r = 0; r < R0; ++r) {
         const int j = ll + L * m + r * (NC / R0);
-        if constexpr (NTEMP) {
+        if constexpr (NTEMP) {   // (streaming loads: 13.7 against 14.4 ms per 2048^3 launch with plain ones)
           v[m * R0 + r] = live ? load_stream(&src[j]) : make_float2(0.f, 0.f);
         } else {
           v[m * R0 + r] = live ? src[j] : make_float2(0.f, 0.f);
@@ -783,8 +783,7 @@ __global__ void __launch_bounds__(TG* L)
       const int tt = idx % T, kk = idx / T, k = kk + h * (NC / 2);
       if (a0 + tt < p.A && min(k, NC - k) <= kc) {
         const cf val = buf[tridx<T>(kk, tt)];
-        long long o = (long long)k * p.out_ok + tt;
-        if constexpr (KG) o += (long long)(k / p.kg) * p.kg_gap;
+        const long long o = (long long)k * p.out_ok + tt;
         if constexpr (NTEMP)
           store_stream(&out[o], val);
         else
@@ -1523,15 +1522,16 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
   // form at the plan's 1024 threads with the lane indices re-materialised per tile (117 VGPRs, no spill): 137.9 ms.  Not kept.)
   typedef PlanInfo<NC> PI;
   constexpr int T = (NC == 1024 && !REAL) ? 16 : transpose_T<NC>();
-  if constexpr (!REAL && wide_transpose<NC>()) {
+  // (single planes -- the Nyquist plane's own launch -- stay with the narrow kernel: nothing to gain there, and the
+  // profiler's per-kernel averages then describe the main launches only)
+  if constexpr (!REAL && wide_transpose<NC>()) if (p.B > 1) {
     // 2 x T lines per workgroup, 128-byte output segments (fft_transpose_pass_wide)
     const size_t lds = transpose_lds_bytes<NC, T>();
     // full 128-byte lines written once: non-temporal stores (2048^3: 3.93 against 4.56 ms per 512-row slab; with the 64-byte
     // segments of the 8-line kernel they were a loss on images this large).  On half the plan's lanes per line (512 threads)
     // the kernel spills 47 registers.
     constexpr int LW = PI::L;
-    auto kern = fft_transpose_pass_wide<NC, T, LW, true, false>;
-    if (p.kg) kern = fft_transpose_pass_wide<NC, T, LW, true, true>;
+    auto kern = fft_transpose_pass_wide<NC, T, LW, true>;
     if (lds > 64 * 1024)
       VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -48,7 +48,7 @@ json.dump(summary, open(dst + "_pmc_summary.json", "w"), indent=1)
 
 # main launch of each hot kernel family per config (template arguments carry the line length: N = 2048 -> C4, ...)
 fam = {
-    "C4": {"fft_z": "pencil_fft_z_kernel<1024, 8, false>", "fft_y": "fft_transpose_pass<2048, 8, false, false, false",
+    "C4": {"fft_z": "pencil_fft_z_kernel<1024, 8, false>", "fft_y": "fft_transpose_pass_wide<2048, 8, 128, true>",
            "fft_x": "fft_x_pass<2048, 2, 0"},
     "C2": {"fft_z": "pencil_fft_z_kernel<256, 16, false>", "fft_y": "fft_transpose_pass<512, 16, false, true, false",
            "fft_x": "fft_x_pass<512, 8, 0"},
