@@ -24,6 +24,11 @@
 
 #include "vps_internal.h"
 
+// Timing-only build switches (never defined by the product build; results are wrong or incomplete with them -- they exist so
+// that the ablations quoted in DESIGN.md can be repeated with tools/build_variant.sh + tools/time_pencil.py / time_xpass.py):
+//   VPS_PENCIL_NOSTORE  pencil kernel without its global stores      VPS_ABL_NOZERO / VPS_ABL_NOSCATTER  ... without the
+//   VPS_ABL_NOFFT       ... without transform, image and stores      accumulator's zero-fill / the LDS adds
+//   VPS_ABL_X_NOATOMIC / VPS_ABL_X_NOBIN   x pass without the LDS shell atomics / without the shell search and binning
 namespace {
 
 typedef float2 cf;
@@ -550,19 +555,8 @@ __device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf*
       const cf wd = cmul(w, d);
       if (ok) {
         // -i * wd = (wd.y, -wd.x);  for NC-k: conj(sm) and -i * conj(wd) = (-wd.y, -wd.x)
-#ifdef VPS_PENCIL_FAKE128
-        if (T == 8 && !BOUNDS) {   // TIMING ONLY (wrong addresses): the same stores as 128-byte segments
-          const int par = (int)((reinterpret_cast<unsigned long long>(out) >> 6) & 1);
-          cf* o16 = out - 8 * par;
-          const int k2 = NC - k;
-          store_stream(&o16[(long long)((k & ~1) + par) * out_ok + tt + 8 * (k & 1)], make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x)));
-          store_stream(&o16[(long long)((k2 & ~1) + par) * out_ok + tt + 8 * (k2 & 1)], make_float2(0.5f * (sm.x - wd.y), 0.5f * (-sm.y - wd.x)));
-        } else
-#endif
-        {
         store_stream(&out[(long long)k * out_ok + tt], make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x)));
         store_stream(&out[(long long)(NC - k) * out_ok + tt], make_float2(0.5f * (sm.x - wd.y), 0.5f * (-sm.y - wd.x)));
-        }
       }
     }
   }
