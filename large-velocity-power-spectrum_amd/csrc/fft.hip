@@ -704,23 +704,28 @@ __global__ void __launch_bounds__(TG* L)
   const cf* tw = PI::TWLDS ? tw_lds : p.tw_stage;
 
   const int tid = threadIdx.x;
-  const int t = tid / L, l = tid % L;
-  const int tiles = (p.A + T - 1) / T;
-  const unsigned bid = blockIdx.x;
-  const int bo = bid / tiles;                 // batch as the output sees it
-  const int a0 = (bid % tiles) * T;
-  const long long b = p.bg ? (long long)(bo / p.bg) * p.bg_in + p.b_off + bo % p.bg : bo;   // batch as the input sees it
-  const long long ogap = p.bg ? (long long)(bo / p.bg) * p.bg_gap : 0;
+  const unsigned tiles = (unsigned)((p.A + T - 1) / T);
+  const unsigned ntiles = tiles * (unsigned)p.B;   // (the launcher checks that this fits)
 
   if constexpr (PI::TWLDS)
     for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
 
-  // stage-0 inputs of line a0 + line of a thread `who` (the thread index, possibly laundered -- see below)
-  auto load_line = [&](cf (&v)[RL], int who, int first) {
+  // Register budget: 1024 threads leave 128 VGPRs, and two groups' values are 64 of them.  Left to itself the compiler
+  // forms the LDS / global addresses of BOTH transforms and of the store loops once, ahead of the first transform, and
+  // keeps ~40 of them live throughout (84 bytes per lane spilled, +4 % run time).  A thread index passed through an
+  // empty asm is a new value to it: addresses derived from it are formed where they are used.
+  auto fresh = [](int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+  };
+  // stage-0 inputs of line `first` + (line of thread `who`) of tile `tile` (who: the thread index, possibly laundered)
+  auto load_line = [&](cf (&v)[RL], unsigned tile, int who, int first) {
     constexpr int R0 = PI::R0, NB = RL / R0;
+    const int bo_ = (int)(tile / tiles), a0_ = (int)(tile % tiles) * T;
+    const long long b_ = p.bg ? (long long)(bo_ / p.bg) * p.bg_in + p.b_off + bo_ % p.bg : bo_;
     const int tl = who / L, ll = who % L;
-    const bool live = (a0 + first + tl) < p.A;
-    const cf* src = reinterpret_cast<const cf*>(p.in) + (long long)b * p.in_sb + (long long)(a0 + first + tl) * p.in_sa;
+    const bool live = (a0_ + first + tl) < p.A;
+    const cf* src = reinterpret_cast<const cf*>(p.in) + b_ * p.in_sb + (long long)(a0_ + first + tl) * p.in_sa;
 #pragma unroll
     for (int m = 0; m < NB; ++m)
 #pragma unroll
@@ -733,60 +738,67 @@ __global__ void __launch_bounds__(TG* L)
         }
       }
   };
-  // Register budget: 1024 threads leave 128 VGPRs, and two groups' values are 64 of them.  Left to itself the compiler
-  // forms the LDS / global addresses of BOTH transforms and of the store loops once, ahead of the first transform, and
-  // keeps ~40 of them live throughout (84 bytes per lane spilled, +4 % run time).  A thread index passed through an
-  // empty asm is a new value to it: addresses derived from it are formed where they are used.
-  auto fresh = [](int x) {
-    asm volatile("" : "+v"(x));
-    return x;
-  };
-  cf v0[RL], v1[RL];
-  load_line(v0, tid, 0);
-  __syncthreads();  // twiddle image visible
   constexpr bool WSYNC = (L <= 64) && (64 % L == 0);
-  fft_from_regs_l<NC, L, WSYNC>(v0, buf + t * PI::PITCH, tw, l);
-  // (requesting the second group ahead of the first transform measured 14.1 against 13.6 ms per 2048^3 launch; from
-  // inside it, before its last butterflies, 13.55)
-  load_line(v1, fresh(tid), TG);
-  __syncthreads();  // every lane done with the per-line buffers
-  {
-    const int tidb = fresh(tid);
-    fft_from_regs_l<NC, L, WSYNC>(v1, buf + (tidb / L) * PI::PITCH, tw, tidb % L);
-  }
+  // Persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...  ONE 1024-thread workgroup fits a CU, so nothing else
+  // would overlap a tile's first loads or its last stores: the next tile's first group is requested as soon as the registers
+  // of the current tile's lower half are free -- it flies behind the second half's image and stores.
+  cf v0[RL], v1[RL];
+  unsigned tile = blockIdx.x;
+  if (tile < ntiles) load_line(v0, tile, tid, 0);
+  __syncthreads();  // twiddle image visible
+  for (; tile < ntiles; tile = (ntiles - tile > gridDim.x) ? tile + gridDim.x : ntiles) {
+    const int bo = (int)(tile / tiles);                 // batch as the output sees it
+    const int a0 = (int)(tile % tiles) * T;
+    const long long b = p.bg ? (long long)(bo / p.bg) * p.bg_in + p.b_off + bo % p.bg : bo;   // batch as the input sees it
+    const long long ogap = p.bg ? (long long)(bo / p.bg) * p.bg_gap : 0;
+    {
+      const int tida = fresh(tid);
+      fft_from_regs_l<NC, L, WSYNC>(v0, buf + (tida / L) * PI::PITCH, tw, tida % L);
+    }
+    // (requesting the second group ahead of the first transform: 14.1 against 12.4 ms per 2048^3 launch)
+    load_line(v1, tile, fresh(tid), TG);
+    __syncthreads();  // every lane done with the per-line buffers
+    {
+      const int tidb = fresh(tid);
+      fft_from_regs_l<NC, L, WSYNC>(v1, buf + (tidb / L) * PI::PITCH, tw, tidb % L);
+    }
 
-  cf* out = reinterpret_cast<cf*>(p.out) + (long long)bo * p.out_ob + ogap + a0;
-  const int kc = p.kcut ? p.kcut[p.kz_fixed >= 0 ? p.kz_fixed : (int)b] : NC;
+    cf* out = reinterpret_cast<cf*>(p.out) + (long long)bo * p.out_ob + ogap + a0;
+    const int kc = p.kcut ? p.kcut[p.kz_fixed >= 0 ? p.kz_fixed : (int)b] : NC;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();  // exchange buffers / the previous half image are free
-    const int tid2 = fresh(tid);
+    for (int h = 0; h < 2; ++h) {
+      __syncthreads();  // exchange buffers / the previous half image are free
+      const int tid2 = fresh(tid);
 #pragma unroll
-    for (int i = 0; i < RL; ++i) {
-      if (((i % R) >= R / 2) == (h == 1)) {
-        const int k = out_index_l<NC, L>(tid2 % L, i) - h * (NC / 2);
-        buf[tridx<T>(k, tid2 / L)] = v0[i];
-        buf[tridx<T>(k, tid2 / L + TG)] = v1[i];
+      for (int i = 0; i < RL; ++i) {
+        if (((i % R) >= R / 2) == (h == 1)) {
+          const int k = out_index_l<NC, L>(tid2 % L, i) - h * (NC / 2);
+          buf[tridx<T>(k, tid2 / L)] = v0[i];
+          buf[tridx<T>(k, tid2 / L + TG)] = v1[i];
+        }
       }
-    }
-    __syncthreads();
-    constexpr int IT = (NC / 2) * T / NT;
+      // the lower halves are in the image, the upper halves just went: v0 takes the next tile's first group
+      // (requested after the barrier instead: 12.96 against 12.43 ms)
+      if (h == 1 && ntiles - tile > gridDim.x) load_line(v0, tile + gridDim.x, fresh(tid), 0);
+      __syncthreads();
+      constexpr int IT = (NC / 2) * T / NT;
 #pragma unroll 4
-    for (int i = 0; i < IT; ++i) {
-      const int idx = tid2 + i * NT;
-      const int tt = idx % T, kk = idx / T, k = kk + h * (NC / 2);
-      if (a0 + tt < p.A && min(k, NC - k) <= kc) {
-        const cf val = buf[tridx<T>(kk, tt)];
-        const long long o = (long long)k * p.out_ok + tt;
-        if constexpr (NTEMP)
-          store_stream(&out[o], val);
-        else
-          out[o] = val;
+      for (int i = 0; i < IT; ++i) {
+        const int idx = tid2 + i * NT;
+        const int tt = idx % T, kk = idx / T, k = kk + h * (NC / 2);
+        if (a0 + tt < p.A && min(k, NC - k) <= kc) {
+          const cf val = buf[tridx<T>(kk, tt)];
+          const long long o = (long long)k * p.out_ok + tt;
+          if constexpr (NTEMP)
+            store_stream(&out[o], val);
+          else
+            out[o] = val;
+        }
       }
     }
+    __syncthreads();  // the image is consumed before the next tile's exchanges overwrite it
   }
 }
-
 
 // ------------------------------------------------------------------------------
 // Fused deposit + field algebra + z pass ("pencil" kernel).  A pencil is the TP z-lines
@@ -1530,8 +1542,12 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
       VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long tiles = (p.A + 2 * T - 1) / (2 * T);
-    const long long grid = tiles * p.B;
+    long long grid = tiles * p.B;
     if (grid <= 0 || grid > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_ARG, "fft grid out of range");
+    // as many workgroups as fit the chip at once (one per CU at 2048), each walking its share of the tiles: 2048^3 launch
+    // 13.4 -> 12.4 ms, a 256-row slab 1.80 -> 1.63 ms against one workgroup per tile
+    const long long per_cu = (long long)(ctx->lds_per_cu / lds) > 0 ? (long long)(ctx->lds_per_cu / lds) : 1;
+    if (grid > (long long)ctx->num_cu * per_cu) grid = (long long)ctx->num_cu * per_cu;
     {
       vps_launch_timer tm(ctx, kind);
       hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(T * LW), lds, ctx->stream, p);
