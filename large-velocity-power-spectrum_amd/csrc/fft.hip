@@ -1044,6 +1044,10 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
   }
 }
 
+// (A persistent form of the pencil kernel -- workgroups walking pencil slots, the next pencil's bucket bounds, cells and
+// first values requested behind the last component's stores -- measured slower: 32.5 against 30.6 ms per C4 vector launch,
+// 16.1 against 13.0 for energy, 0.48 against 0.39 ms at C2.  Unlike the y pass's tiles, pencils differ in work; the
+// hardware dispatcher balances them, a fixed stride does not.)
 // y-lines per pencil: 16 (128-byte output segments); 8 for 2048-cell lines, on half the plan's lanes (pencil_lanes): 256
 // threads and 76 KB of LDS per workgroup, so TWO workgroups share a CU and one's stores overlap the other's LDS work.  The two
 // pencils that complete a 128-byte output line are placed on one XCD (remap in the kernel); 38 % of the lines still
