@@ -26,6 +26,8 @@
 // compiled without floating-point contraction.
 #pragma clang fp contract(off)
 
+#include <type_traits>
+
 #include "vps_internal.h"
 #include "scan.h"
 
@@ -220,14 +222,22 @@ struct SortGeom {
   long long nbuckets, nchunks;
 };
 
-__device__ __forceinline__ unsigned sort_bucket_of(unsigned key, const SortGeom& g) {
-  return g.cshift >= 0 ? (key >> g.cshift) : (key / g.cells);
+// Keys.  The full key of a particle is bucket * cells + cell-in-bucket: K = unsigned while that fits 32 bits, unsigned long
+// long beyond (C4 on one GPU: 2^19 pencils x 2^14 cells).  It only lives in the keys[] array between the level-1 histogram
+// and the level-1 scatter; the level-1 RECORD carries the key relative to its group's first bucket (< 2^gshift * cells),
+// which is all level 2 -- one workgroup per group -- needs, and always 32 bits.
+template <typename K>
+__device__ __forceinline__ constexpr K sort_invalid() { return (K)~(K)0; }
+
+template <typename K>
+__device__ __forceinline__ unsigned sort_bucket_of(K key, const SortGeom& g) {
+  return (unsigned)(g.cshift >= 0 ? (key >> g.cshift) : (key / g.cells));
 }
 
-template <typename F>
+template <typename F, typename K>
 __global__ void __launch_bounds__(SORT_THREADS)
     sort_hist_kernel(const F* __restrict__ pos, long long np, F lcell, F nsize, Bricks b, SortGeom g,
-                     unsigned* __restrict__ keys, unsigned* __restrict__ table) {
+                     K* __restrict__ keys, unsigned* __restrict__ table) {
   extern __shared__ unsigned sort_lds[];
   for (int i = threadIdx.x; i < g.ngroups; i += SORT_THREADS) sort_lds[i] = 0;
   __syncthreads();
@@ -236,9 +246,10 @@ __global__ void __launch_bounds__(SORT_THREADS)
   for (int k = 0; k < SORT_ITEMS; ++k) {
     const long long i = base + (long long)k * SORT_THREADS + threadIdx.x;
     if (i < np) {
-      unsigned brick, loc, key = SORT_INVALID;
+      unsigned brick, loc;
+      K key = sort_invalid<K>();
       if (locate<F>(pos, i, lcell, nsize, b, brick, loc)) {
-        key = brick * g.cells + loc;
+        key = (K)brick * g.cells + loc;
         atomicAdd(&sort_lds[brick >> g.gshift], 1u);
       }
       keys[i] = key;
@@ -268,9 +279,9 @@ __device__ __forceinline__ void load_payload(const float* __restrict__ payload, 
   }
 }
 
-template <int C, bool RHOV>
+template <int C, bool RHOV, typename K>
 __global__ void __launch_bounds__(SORT_THREADS)
-    sort_scatter_kernel(const unsigned* __restrict__ keys, const float* __restrict__ payload,
+    sort_scatter_kernel(const K* __restrict__ keys, const float* __restrict__ payload,
                         const float* __restrict__ rho, long long np, SortGeom g,
                         const unsigned* __restrict__ table_start, unsigned* __restrict__ rec1) {
   extern __shared__ unsigned sort_lds[];
@@ -282,14 +293,15 @@ __global__ void __launch_bounds__(SORT_THREADS)
   for (int k = 0; k < SORT_ITEMS; ++k) {
     const long long i = base + (long long)k * SORT_THREADS + threadIdx.x;
     if (i >= np) continue;
-    const unsigned key = keys[i];
-    if (key == SORT_INVALID) continue;
+    const K key = keys[i];
+    if (key == sort_invalid<K>()) continue;
     float val[C];
     load_payload<C, RHOV>(payload, rho, i, val);
-    const unsigned slot = atomicAdd(&sort_lds[sort_bucket_of(key, g) >> g.gshift], 1u);
+    const unsigned grp = sort_bucket_of<K>(key, g) >> g.gshift;
+    const unsigned slot = atomicAdd(&sort_lds[grp], 1u);
     constexpr int W = sort_rec1_words(C);
     unsigned w[W];
-    w[0] = key;
+    w[0] = (unsigned)(key - (K)((unsigned long long)grp << g.gshift) * g.cells);   // relative to the group's first bucket
 #pragma unroll
     for (int c = 0; c < C; ++c) w[1 + c] = __float_as_uint(val[c]);
 #pragma unroll
@@ -352,9 +364,9 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned* a, int n, uns
 // of 64 scattered dwords per instruction.  Consecutive chunks own adjacent runs of every group:
 // they are dealt to the SAME XCD (blockIdx % 8, speed only) so that its L2 can merge the partly
 // written lines at run boundaries.
-template <int C, bool RHOV>
+template <int C, bool RHOV, typename K>
 __global__ void __launch_bounds__(SORT_THREADS)
-    sort_scatter_staged_kernel(const unsigned* __restrict__ keys, const float* __restrict__ payload,
+    sort_scatter_staged_kernel(const K* __restrict__ keys, const float* __restrict__ payload,
                                const float* __restrict__ rho, long long np, SortGeom g,
                                const unsigned* __restrict__ table_start, unsigned* __restrict__ rec1) {
   constexpr int W = sort_rec1_words(C);
@@ -373,18 +385,19 @@ __global__ void __launch_bounds__(SORT_THREADS)
   }
   __syncthreads();
   const long long base = chunk * SORT_CHUNK;
-  unsigned key[SORT_ITEMS], grp[SORT_ITEMS], rk[SORT_ITEMS];
+  K key[SORT_ITEMS];
+  unsigned grp[SORT_ITEMS], rk[SORT_ITEMS];
   float val[SORT_ITEMS][C];
 #pragma unroll
   for (int k = 0; k < SORT_ITEMS; ++k) {
     const long long i = base + (long long)k * SORT_THREADS + threadIdx.x;
-    key[k] = (i < np) ? keys[i] : SORT_INVALID;
-    if (key[k] != SORT_INVALID) load_payload<C, RHOV>(payload, rho, i, val[k]);
+    key[k] = (i < np) ? keys[i] : sort_invalid<K>();
+    if (key[k] != sort_invalid<K>()) load_payload<C, RHOV>(payload, rho, i, val[k]);
   }
 #pragma unroll
   for (int k = 0; k < SORT_ITEMS; ++k) {
-    if (key[k] != SORT_INVALID) {
-      grp[k] = sort_bucket_of(key[k], g) >> g.gshift;
+    if (key[k] != sort_invalid<K>()) {
+      grp[k] = sort_bucket_of<K>(key[k], g) >> g.gshift;
       rk[k] = atomicAdd(&lstart[grp[k]], 1u);
     }
   }
@@ -392,10 +405,10 @@ __global__ void __launch_bounds__(SORT_THREADS)
   const unsigned total = block_exclusive_scan<SORT_THREADS>(lstart, g.ngroups, scratch);
 #pragma unroll
   for (int k = 0; k < SORT_ITEMS; ++k) {
-    if (key[k] != SORT_INVALID) {
+    if (key[k] != sort_invalid<K>()) {
       const unsigned p = lstart[grp[k]] + rk[k];
       gdest[p] = gbase[grp[k]] + rk[k];
-      stage[p * W] = key[k];
+      stage[p * W] = (unsigned)(key[k] - (K)((unsigned long long)grp[k] << g.gshift) * g.cells);   // relative to the group's first bucket
 #pragma unroll
       for (int c = 0; c < C; ++c) stage[p * W + 1 + c] = __float_as_uint(val[k][c]);
     }
@@ -435,7 +448,7 @@ __global__ void __launch_bounds__(FINE_THREADS)
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (key[u] != SORT_INVALID) atomicAdd(&cur[sort_bucket_of(key[u], g) & (G - 1)], 1u);
+      if (key[u] != SORT_INVALID) atomicAdd(&cur[sort_bucket_of<unsigned>(key[u], g) & (G - 1)], 1u);   // (keys relative to the group)
   }
   __syncthreads();
   block_exclusive_scan<FINE_THREADS>(cur, G, scratch);
@@ -462,7 +475,7 @@ __global__ void __launch_bounds__(FINE_THREADS)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (r[u][0] == SORT_INVALID) continue;
-      const unsigned bucket = sort_bucket_of(r[u][0], g);
+      const unsigned bucket = sort_bucket_of<unsigned>(r[u][0], g);
       const size_t slot = atomicAdd(&cur[bucket & (G - 1)], 1u);
       unsigned* dst = records + slot * W;
       dst[0] = r[u][0] - bucket * g.cells;
@@ -765,6 +778,7 @@ struct DepLayout {
   size_t count, start, tiles, keys, ranks, records, table, table_start, table_tiles, rec1, total;
   long long nbricks;
   bool two_level;
+  bool wide_keys;   // bucket * cells + cell does not fit 32 bits: 64-bit keys[] (the level-1 records stay 32-bit, see SortGeom)
   SortGeom geom;
 };
 
@@ -807,8 +821,9 @@ DepLayout dep_layout(int64_t np, int C, const Bricks& b) {
   while (((l.nbricks + (1ll << g.gshift) - 1) >> g.gshift) > sort_target_groups()) ++g.gshift;
   g.ngroups = (int)((l.nbricks + (1ll << g.gshift) - 1) >> g.gshift);
   g.nchunks = (np + SORT_CHUNK - 1) / SORT_CHUNK;
-  l.two_level = !sort_force_atomic() && g.gshift <= 12 &&
-                (unsigned long long)l.nbricks * (unsigned long long)b.cells < 0xffffffffull;
+  l.wide_keys = (unsigned long long)l.nbricks * (unsigned long long)b.cells >= 0xffffffffull;
+  l.two_level = !sort_force_atomic() && g.gshift <= 12 && l.nbricks < 0x7fffffffLL &&
+                ((unsigned long long)b.cells << g.gshift) < 0xffffffffull;
   const long long ntable = (long long)g.ngroups * g.nchunks;
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t off = 0;
@@ -843,30 +858,38 @@ int sort_into_buckets(vps_ctx* ctx, const F* pos, const float* payload, const fl
   }
   if (l.two_level) {
     const SortGeom& g = l.geom;
-    unsigned* keys = reinterpret_cast<unsigned*>(work + l.keys);
     unsigned* table = reinterpret_cast<unsigned*>(work + l.table);
     unsigned* table_start = reinterpret_cast<unsigned*>(work + l.table_start);
     unsigned* table_tiles = reinterpret_cast<unsigned*>(work + l.table_tiles);
     unsigned* rec1 = reinterpret_cast<unsigned*>(work + l.rec1);
     const size_t lds1 = sizeof(unsigned) * g.ngroups;
     const size_t lds2 = sizeof(unsigned) * ((1u << g.gshift) + FINE_THREADS / 64);
-    hipLaunchKernelGGL(sort_hist_kernel<F>, dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1, ctx->stream, pos,
-                       (long long)np, lcell, nsz, b, g, keys, table);
-    launch_exclusive_scan(ctx->stream, table, (long long)g.ngroups * g.nchunks, table_tiles, table_start);
     const size_t lds_staged = sizeof(unsigned) * (2 * (size_t)g.ngroups + SORT_THREADS / 64 +
                                                    (size_t)SORT_CHUNK * (1 + sort_rec1_words(C)));
-    if (sort_staged() && lds_staged <= ctx->lds_per_cu) {
-      auto kern = sort_scatter_staged_kernel<C, RHOV>;
-      if (lds_staged > 64 * 1024)
-        VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
-      const unsigned grid = (unsigned)(8 * ((g.nchunks + 7) / 8));
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(SORT_THREADS), lds_staged, ctx->stream, keys, payload, rho,
-                         (long long)np, g, table_start, rec1);
-    } else {
-      hipLaunchKernelGGL((sort_scatter_kernel<C, RHOV>), dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1,
-                         ctx->stream, keys, payload, rho, (long long)np, g, table_start, rec1);
-    }
+    const bool staged = sort_staged() && lds_staged <= ctx->lds_per_cu;
+    auto level1 = [&](auto* keys) -> int {
+      typedef typename std::remove_pointer<decltype(keys)>::type K;
+      hipLaunchKernelGGL((sort_hist_kernel<F, K>), dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1, ctx->stream, pos,
+                         (long long)np, lcell, nsz, b, g, keys, table);
+      launch_exclusive_scan(ctx->stream, table, (long long)g.ngroups * g.nchunks, table_tiles, table_start);
+      if (staged) {
+        auto kern = sort_scatter_staged_kernel<C, RHOV, K>;
+        if (lds_staged > 64 * 1024)
+          VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
+        const unsigned grid = (unsigned)(8 * ((g.nchunks + 7) / 8));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SORT_THREADS), lds_staged, ctx->stream, keys, payload, rho,
+                           (long long)np, g, table_start, rec1);
+      } else {
+        hipLaunchKernelGGL((sort_scatter_kernel<C, RHOV, K>), dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1,
+                           ctx->stream, keys, payload, rho, (long long)np, g, table_start, rec1);
+      }
+      return VPS_OK;
+    };
+    // (the keys[] region holds 8 bytes per particle either way: the atomic-rank path's keys are 64-bit)
+    const int rc1 = l.wide_keys ? level1(reinterpret_cast<unsigned long long*>(work + l.keys))
+                                : level1(reinterpret_cast<unsigned*>(work + l.keys));
+    if (rc1) return rc1;
     hipLaunchKernelGGL(sort_fine_kernel<C>, dim3((unsigned)g.ngroups), dim3(FINE_THREADS), lds2, ctx->stream, rec1,
                        g, table_start, start, records);
   } else {
