@@ -1174,7 +1174,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   constexpr int TH = (T >= 2) ? T / 2 : 1;
   // tile -> this lane's line, and the loads of its stage-0 inputs
   long long li = 0;
-  bool live = false, mirrored = false, has_partner = false;
+  bool live = false, mirrored = false, has_partner = false, beyond = false;
   double k2y = 0.0, k2z = 0.0;   // fl(ky*ky), fl(kz*kz) of the line (MODE 0)
   float wyz = 1.f;               // window factor of the line's (ky, kz)
   unsigned wz = 1u;              // Hermitian multiplicity of its kz plane
@@ -1194,7 +1194,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   auto tile_beyond_shells = [&](long long tile) -> bool {
     if constexpr (MODE == 0 && FAST) {
       if (pair) {
-        const int kz = p.kz0 + (int)(p.line0 / p.N) + (int)(tile / tiles_per_plane);
+        const int kz = p.kz0 + (int)(p.line0 / NC) + (int)(tile / tiles_per_plane);
         return (p.k2[tile_q(tile) * TH] + p.k2[kz]) >= p.thr[p.nbins];
       }
     }
@@ -1213,15 +1213,17 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
       mirrored = ((t & 1) == 1) && (ky_a != 0);
       has_partner = ((t & 1) == 0) && (ky_a != 0);
     }
-    live = li < p.nlines && !tile_beyond_shells(tile);
+    beyond = tile_beyond_shells(tile);   // (kept for the loop below: the test is three table loads deep)
+    live = li < p.nlines && !beyond;
     if constexpr (MODE == 0) {
       if (live) {
         const long long g = p.line0 + li;
-        const int kz = p.kz0 + (int)(g / p.N);
-        k2y = p.k2[(int)(g % p.N)];
+        // (lines of the x pass have N = NC points: a compile-time divisor instead of a 64-bit division per tile and thread)
+        const int kz = p.kz0 + (int)(g / NC);
+        k2y = p.k2[(int)(g % NC)];
         k2z = p.k2[kz];
-        wz = (kz == 0 || 2 * kz == p.N) ? 1u : 2u;
-        if (p.win) wyz = p.win[(int)(g % p.N)] * p.win[kz];
+        wz = (kz == 0 || 2 * kz == NC) ? 1u : 2u;
+        if (p.win) wyz = p.win[(int)(g % NC)] * p.win[kz];
       }
     }
   };
@@ -1255,7 +1257,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
     load_line(v, 0, l);
   }
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    if (tile_beyond_shells(tile)) {   // (uniform over the workgroup) nothing to bin here: only keep the prefetch chain going
+    if (beyond) {   // (uniform over the workgroup; set by locate_line(tile)) nothing to bin here: only keep the prefetch chain going
       if (tile + gridDim.x < ntiles) {
         locate_line(tile + gridDim.x);
         load_line(v, 0, l);
