@@ -1174,7 +1174,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   constexpr int TH = (T >= 2) ? T / 2 : 1;
   // tile -> this lane's line, and the loads of its stage-0 inputs
   long long li = 0;
-  bool live = false, mirrored = false, has_partner = false, beyond = false;
+  bool live = false, mirrored = false, has_partner = false;
   double k2y = 0.0, k2z = 0.0;   // fl(ky*ky), fl(kz*kz) of the line (MODE 0)
   float wyz = 1.f;               // window factor of the line's (ky, kz)
   unsigned wz = 1u;              // Hermitian multiplicity of its kz plane
@@ -1213,8 +1213,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
       mirrored = ((t & 1) == 1) && (ky_a != 0);
       has_partner = ((t & 1) == 0) && (ky_a != 0);
     }
-    beyond = tile_beyond_shells(tile);   // (kept for the loop below: the test is three table loads deep)
-    live = li < p.nlines && !beyond;
+    live = li < p.nlines && !tile_beyond_shells(tile);
     if constexpr (MODE == 0) {
       if (live) {
         const long long g = p.line0 + li;
@@ -1257,7 +1256,8 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
     load_line(v, 0, l);
   }
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    if (beyond) {   // (uniform over the workgroup; set by locate_line(tile)) nothing to bin here: only keep the prefetch chain going
+    // (carrying the flag over from the prefetch's locate_line instead of testing again: -2 % at 2048, +30 % at 512 -- not kept)
+    if (tile_beyond_shells(tile)) {   // (uniform over the workgroup) nothing to bin here: only keep the prefetch chain going
       if (tile + gridDim.x < ntiles) {
         locate_line(tile + gridDim.x);
         load_line(v, 0, l);
