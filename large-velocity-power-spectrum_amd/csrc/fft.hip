@@ -680,7 +680,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
 
 
 // ------------------------------------------------------------------------------
-// Wide transposing y pass for lines whose 16-line tile does not fit LDS (NC > 1024).
+// Wide transposing y pass for lines whose 16-line tile does not fit LDS (NC > 1024) or fills it (NC = 1024).
 // What bounds the transposing pass of long lines is the WRITE pattern, not the transform: a plain
 // transposing copy of a 2048^3 half spectrum (tools/micro/transpose_bw.hip) moves 3.9 TB/s with the
 // 64-byte segments of 8-line tiles and 5.5 TB/s with full 128-byte lines -- and fft_transpose_pass<2048, 8>
@@ -690,8 +690,9 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
 // image in two k-halves [NC/2][2 TG] -- after the last radix-R stage register slot (m, r) holds
 // k = l + L m + r NC/R, so r < R/2 is exactly the lower half.
 // ------------------------------------------------------------------------------
+// (1024-point lines: two 512-thread workgroups fit a CU's LDS, so the kernel is held to the 128 VGPRs of four waves per SIMD)
 template <int NC, int TG, int L, bool NTEMP>
-__global__ void __launch_bounds__(TG* L)
+__global__ void __launch_bounds__(TG* L, (NC == 1024 ? 4 : 1))
     fft_transpose_pass_wide(const PassParams p) {
   typedef PlanInfo<NC> PI;
   constexpr int RL = NC / L, NT = TG * L, T = 2 * TG;
@@ -1508,7 +1509,10 @@ constexpr bool wide_transpose() {
 #ifdef VPS_Y_NO_WIDE
   return false;
 #else
-  return NC == 1536 || NC == 2048 || NC == 4096;   // (2000: 800 threads x 2 x 20 points do not fit 128 VGPRs)
+  // 1024: the 16-line tile fits LDS as ONE 1024-thread workgroup per CU (1.80 ms per 1024^3 launch); as two groups of 8 it is
+  // two persistent 512-thread workgroups per CU: 1.58 ms.  512 (32 lines, 256-byte segments): 0.20 -> 0.21 ms, not taken.
+  // 2000: 800 threads x 2 x 20 points do not fit 128 VGPRs.
+  return NC == 1024 || NC == 1536 || NC == 2048 || NC == 4096;
 #endif
 }
 
@@ -1538,16 +1542,17 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
   // profiler's per-kernel averages then describe the main launches only)
   if constexpr (!REAL && wide_transpose<NC>()) if (p.B > 1) {
     // 2 x T lines per workgroup, 128-byte output segments (fft_transpose_pass_wide)
-    const size_t lds = transpose_lds_bytes<NC, T>();
+    constexpr int TGW = transpose_T<NC>();   // lines per group
+    const size_t lds = transpose_lds_bytes<NC, TGW>();
     // full 128-byte lines written once: non-temporal stores (2048^3: 3.93 against 4.56 ms per 512-row slab; with the 64-byte
     // segments of the 8-line kernel they were a loss on images this large).  On half the plan's lanes per line (512 threads)
     // the kernel spills 47 registers.
     constexpr int LW = PI::L;
-    auto kern = fft_transpose_pass_wide<NC, T, LW, true>;
+    auto kern = fft_transpose_pass_wide<NC, TGW, LW, true>;
     if (lds > 64 * 1024)
       VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long long tiles = (p.A + 2 * T - 1) / (2 * T);
+    const long long tiles = (p.A + 2 * TGW - 1) / (2 * TGW);
     long long grid = tiles * p.B;
     if (grid <= 0 || grid > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_ARG, "fft grid out of range");
     // as many workgroups as fit the chip at once (one per CU at 2048), each walking its share of the tiles: 2048^3 launch
@@ -1556,7 +1561,7 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
     if (grid > (long long)ctx->num_cu * per_cu) grid = (long long)ctx->num_cu * per_cu;
     {
       vps_launch_timer tm(ctx, kind);
-      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(T * LW), lds, ctx->stream, p);
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TGW * LW), lds, ctx->stream, p);
     }
     VPS_HIP_CHECK(ctx, hipGetLastError());
     return VPS_OK;
