@@ -52,7 +52,7 @@ fam = {
            "fft_x": "fft_x_pass<2048, 2, 0"},
     "C2": {"fft_z": "pencil_fft_z_kernel<256, 16, false>", "fft_y": "fft_transpose_pass<512, 16, false, true, false",
            "fft_x": "fft_x_pass<512, 8, 0"},
-    "C3": {"fft_z": "fft_transpose_pass<512, 8, true", "fft_y": "fft_transpose_pass<1024, 16, false",
+    "C3": {"fft_z": "fft_transpose_pass<512, 8, true", "fft_y": "fft_transpose_pass_wide<1024, 8, 64, true>",
            "fft_x": "fft_x_pass<1024, 4, 0", "nn_query": "nn_scatter_kernel<float, 4>"},
 }
 traffic = {"_note": "HBM bytes of the MAIN (largest) launch of each hot kernel, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in "
