@@ -356,7 +356,20 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     wl = Workload(K, comm, N, L, route, quantities, flavour, dpos, dvel, drho, unfused=args.unfused)
     nx = wl.nx
     nchunks = wl.pipe.nchunks
-    wl_keep = wl.pipe.kept_row_fraction(comm.rank * (N // 2 // G), (comm.rank + 1) * (N // 2 // G)) if G > 1 else wl.pipe.kept_row_fraction()
+    exchange_rows = None
+    if G > 1 and wl.pipe.chunked:
+        # a rank receives nkc planes of every band of G*nkc planes (vps_fft_y_chunk_kz0): the rows it keeps, and the rows per
+        # plane that cross the node (the blocks carry only the rows a plane of the band can still need: vps_fft_y_chunk_rows)
+        nkc_ = N // 2 // G // nchunks
+        wl_keep = float(np.mean([wl.pipe.kept_row_fraction(c * G * nkc_ + comm.rank * nkc_, c * G * nkc_ + (comm.rank + 1) * nkc_)
+                                 for c in range(nchunks)]))
+        wl.pipe.prepare()
+        with wl.pipe._bin_scope():
+            exchange_rows = float(np.mean([K.chunk_rows(N, G, nchunks, c) for c in range(nchunks)])) / N
+    elif G > 1:
+        wl_keep = wl.pipe.kept_row_fraction(comm.rank * (N // 2 // G), (comm.rank + 1) * (N // 2 // G))
+    else:
+        wl_keep = wl.pipe.kept_row_fraction()
     nkz, nky, NH = N // 2 // G, N // G, N // 2
     nfields = wl.fields_per_step()
 
@@ -433,7 +446,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
                    "deviation": rehearsal or (("strong-scaled over %d GPU(s) of one node" % world) if cfg in ("C4", "C5") and world != 8 else None),
                    "grid": N, "particles": Np, "route": route, "quantities": list(quantities),
                    "scalar_fields_per_step": nfields, "path": wl.describe_path(),
-                   "parallelism": ("x-slab x%d, one message per field and pair of ranks in %d kz chunks (Nyquist rows inside it)"
+                   "parallelism": ("x-slab x%d, one message per field and pair of ranks in %d kz chunks (unbinned rows left out, Nyquist rows inside it)"
                                    % (world, nchunks)) if (G == world and world > 1) else "one GPU, no exchange" if G == world else ("EMULATED rank 0 of %d on one GPU, exchanges skipped (diagnostic)" % G)},
         "data": data,
         "particles_per_s": Np / (grid_ms * 1e-3) if grid_ms > 0 else None,
@@ -452,6 +465,8 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
         "per_kernel_frac_of_hbm_peak": {k: step_bytes[k] / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS for k in kms},
         "kept_row_fraction": keep,
     }
+    if exchange_rows is not None:
+        res["exchange_row_fraction"] = exchange_rows   # rows per kz plane in the exchanged blocks / N
     finite = all(np.isfinite(t[:, 2]).all() and t[:, 3].sum() > 0 for t in tabs.values())
     if rank == 0 and not os.environ.get("VPS_BENCH_NOCHECK"):      # (timing-only kernel variants produce garbage)
         assert finite, "non-finite shell sums"

@@ -249,6 +249,7 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
   // fl(ky^2 + kz^2) >= thr[nbins]; x-pass tiles hold up to 16 consecutive |ky|, hence the round-up)
   if (ctx->d_kcut) VPS_HIP_CHECK(ctx, hipFree(ctx->d_kcut));
   ctx->d_kcut = nullptr;
+  ctx->h_kcut.clear();
   if (fast && N >= 128) {
     std::vector<int> kcut(N / 2 + 1);
     for (int kz = 0; kz <= N / 2; ++kz) {
@@ -259,6 +260,7 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
     }
     VPS_HIP_CHECK(ctx, hipMalloc(&ctx->d_kcut, sizeof(int) * kcut.size()));
     VPS_HIP_CHECK(ctx, hipMemcpy(ctx->d_kcut, kcut.data(), sizeof(int) * kcut.size(), hipMemcpyHostToDevice));
+    ctx->h_kcut = kcut;
   }
   ctx->h_k2.assign(k2_axis_host, k2_axis_host + N);
   ctx->h_thr.assign(thr_host, thr_host + nbins + 1);

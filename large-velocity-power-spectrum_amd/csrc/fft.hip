@@ -503,7 +503,15 @@ struct PassParams {
   // there lies beyond the last shell edge and the binning x pass does not read them.  kz = kz_fixed, or the input batch
   const int* kcut;
   int kz_fixed;
+  // row packing of the chunked exchange (vps_fft_y inside a binning-only scope): every plane of the launch keeps the
+  // 2 kc_pack + 1 rows |ky| <= kc_pack (kc_pack >= every plane's kcut; out_ob is then (2 kc_pack + 1) rows) -- row ky sits at
+  // position ky, row NC - j at position 2 kc_pack + 1 - j.  -1: all NC rows in place.
+  int kc_pack = -1;
 };
+
+__device__ __forceinline__ int packed_row(int k, int NC, int kc_pack) {
+  return (kc_pack < 0 || k <= kc_pack) ? k : k - (NC - 2 * kc_pack - 1);
+}
 
 // Non-temporal (streaming) access to one complex value: data that is written once for the next pass
 // or read once from the previous one should not displace what the caches hold.
@@ -664,7 +672,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
       const int tt = idx % T, k = idx / T;
       if (a0 + tt < p.A && min(k, NC - k) <= kc) {
         const cf val = buf[tridx<T>(k, tt)];
-        long long o = (long long)k * p.out_ok + tt;
+        long long o = (long long)packed_row(k, NC, p.kc_pack) * p.out_ok + tt;
         if constexpr (KG) o += (long long)(k / p.kg) * p.kg_gap;
         if constexpr (NTEMP)
           store_stream(&out[o], val);
@@ -789,7 +797,7 @@ __global__ void __launch_bounds__(TG* L, (NC == 1024 ? 4 : 1))
         const int tt = idx % T, kk = idx / T, k = kk + h * (NC / 2);
         if (a0 + tt < p.A && min(k, NC - k) <= kc) {
           const cf val = buf[tridx<T>(kk, tt)];
-          const long long o = (long long)k * p.out_ok + tt;
+          const long long o = (long long)packed_row(k, NC, p.kc_pack) * p.out_ok + tt;
           if constexpr (NTEMP)
             store_stream(&out[o], val);
           else
@@ -1112,6 +1120,8 @@ struct XParams {
   float edge0, inv_spacing;
   double* psum;
   unsigned long long* nsample;
+  int rpp;   // rows per kz plane of a PACKED input (vps_fft_y_chunk_rows; 0: all N rows in place): line (plane, ky) sits at row
+             // plane * rpp + (ky <= kc ? ky : ky - (N - rpp)), kc = (rpp - 1) / 2; rows kc < ky < N - kc do not exist
   int pair;  // FAST path: tiles pair ky with N-ky (needs whole ky ranges: line0, nlines multiples of N)
   double* part_sum;    // [grid][nbins] per-workgroup partial shell sums
   unsigned* part_cnt;  // [grid][nbins] per-workgroup partial shell counts
@@ -1174,7 +1184,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   const bool pair = CANPAIR && p.pair;
   constexpr int TH = (T >= 2) ? T / 2 : 1;
   // tile -> this lane's line, and the loads of its stage-0 inputs
-  long long li = 0;
+  long long li = 0, lrow = 0;   // line index inside the launch's range, and the row of the input it is read from
   bool live = false, mirrored = false, has_partner = false;
   double k2y = 0.0, k2z = 0.0;   // fl(ky*ky), fl(kz*kz) of the line (MODE 0)
   float wyz = 1.f;               // window factor of the line's (ky, kz)
@@ -1215,6 +1225,13 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
       has_partner = ((t & 1) == 0) && (ky_a != 0);
     }
     live = li < p.nlines && !tile_beyond_shells(tile);
+    lrow = li;
+    if (p.rpp) {   // packed rows (chunked exchange; line0 = 0): every mode of a row that was not sent lies beyond the last edge
+      const long long plane = li / NC;
+      const int ky = (int)(li % NC), kcp = (p.rpp - 1) / 2;
+      live = live && (ky <= kcp || ky >= NC - kcp);
+      lrow = plane * p.rpp + (ky <= kcp ? ky : ky - (NC - p.rpp));
+    }
     if constexpr (MODE == 0) {
       if (live) {
         const long long g = p.line0 + li;
@@ -1229,7 +1246,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   };
   auto load_line = [&](cf (&v)[RL], int c, int l) {   // l: the lane index (callers inside loops pass an opaque copy)
     constexpr int R = PI::R0, NB = RL / R;
-    const cf* base = (c == 0 ? p.in : (c == 1 ? p.in1 : p.in2)) + li * p.seglen;
+    const cf* base = (c == 0 ? p.in : (c == 1 ? p.in1 : p.in2)) + lrow * p.seglen;
 #pragma unroll
     for (int m = 0; m < NB; ++m)
 #pragma unroll
@@ -1946,6 +1963,28 @@ int64_t vps_fft_y_chunk_elems(int N, int nx, int G, int nchunks, int chunk) {
   return (int64_t)G * (nkc * N * nx + (chunk == nchunks - 1 ? (int64_t)(N / G) * nx : 0));
 }
 
+// Which kz planes a rank receives in chunk `chunk`: the half spectrum is cut into `nchunks` BANDS of G * nkc planes and every
+// rank gets nkc consecutive planes of each band -- so that (a) the planes of one chunk lie close together and can share one
+// row cut (below), and (b) every rank receives planes from all |kz|, i.e. the same share of rows the binning can skip.
+int vps_fft_y_chunk_kz0(int N, int G, int nchunks, int chunk, int rank) {
+  if (G < 1 || nchunks < 1 || N < 2 || (N / 2) % (G * nchunks)) return -1;
+  const int nkc = N / 2 / G / nchunks;
+  return chunk * G * nkc + rank * nkc;
+}
+
+// Rows per kz plane in the send / receive blocks of chunk `chunk`: N, or -- inside a binning-only scope (vps_set_bin_only)
+// with tables that have a row cut -- the 2 kc + 1 rows |ky| <= kc that any plane of the chunk's band can still need.
+int vps_fft_y_chunk_rows(vps_ctx* ctx, int N, int G, int nchunks, int chunk) {
+  if (!ctx) return -1;
+  const int k0 = vps_fft_y_chunk_kz0(N, G, nchunks, chunk, 0);
+  if (k0 < 0) return -1;
+  if (!(ctx->bin_only && ctx->bin_N == N && (int)ctx->h_kcut.size() == N / 2 + 1)) return N;
+  const int nband = N / 2 / nchunks;
+  int kc = 0;
+  for (int kz = k0; kz < k0 + nband; ++kz) kc = ctx->h_kcut[kz] > kc ? ctx->h_kcut[kz] : kc;
+  return 2 * kc + 1 < N ? 2 * kc + 1 : N;
+}
+
 int vps_fft_y(vps_ctx* ctx, int N, int nx, const void* zimg_dev, int G, int nchunks, int chunk, void* out_dev) {
   VPS_ENTER(ctx);
   if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_fft_y: unsupported N=%d", N);
@@ -1959,30 +1998,33 @@ int vps_fft_y(vps_ctx* ctx, int N, int nx, const void* zimg_dev, int G, int nchu
   if (rc) return rc;
   const cf* B = reinterpret_cast<const cf*>(zimg_dev);
   const cf* BN = B + (size_t)nx * NH * N;
-  const long long blk = (long long)nkc * N * nx + (last ? (long long)nky * nx : 0);   // one destination's block
-  // kz rows {h nkz + chunk nkc + j}: launch batch b = h nkc + j
+  const int rows = vps_fft_y_chunk_rows(ctx, N, G, nchunks, chunk);                    // rows per plane (N: not packed)
+  const long long blk = (long long)nkc * rows * nx + (last ? (long long)nky * nx : 0);   // one destination's block
+  (void)nkz;
+  // kz planes {chunk G nkc + h nkc + j} (vps_fft_y_chunk_kz0): launch batch b = h nkc + j reads input batch chunk G nkc + b
   PassParams py{};
   py.in = B;
   py.out = out_dev;
   py.in_sa = (long long)NH * N;
   py.in_sb = N;
-  py.out_ob = (long long)N * nx;
+  py.out_ob = (long long)rows * nx;
   py.out_ok = nx;
   py.A = nx;
   py.B = G * nkc;
   py.tw_stage = ty.tw_stage;
   py.bg = nkc;
-  py.b_off = chunk * nkc;
-  py.bg_in = nkz;
+  py.b_off = chunk * G * nkc;
+  py.bg_in = nkc;
   py.bg_gap = last ? (long long)nky * nx : 0;
   py.kcut = (ctx->bin_only && ctx->bin_N == N) ? ctx->d_kcut : nullptr;
   py.kz_fixed = -1;
+  py.kc_pack = rows < N ? (rows - 1) / 2 : -1;
   rc = route_transpose(ctx, N, 0, py, VPS_K_FFT_Y);
   if (rc || !last) return rc;
   // Nyquist plane: ky rows of destination h go behind that destination's kz rows
   PassParams pn{};
   pn.in = BN;
-  pn.out = reinterpret_cast<cf*>(out_dev) + (long long)nkc * N * nx;
+  pn.out = reinterpret_cast<cf*>(out_dev) + (long long)nkc * rows * nx;
   pn.in_sa = N;
   pn.in_sb = 0;
   pn.out_ob = 0;
@@ -2086,7 +2128,7 @@ extern "C" {
 
 static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const void* in_dev,
                       const void* in1_dev, const void* in2_dev, int ncomp, int nseg, int64_t seg_stride,
-                      int mode, double* psum_dev, unsigned long long* nsample_dev, void* out_dev) {
+                      int mode, double* psum_dev, unsigned long long* nsample_dev, void* out_dev, int rows_per_plane = 0) {
   VPS_ENTER(ctx);
   if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   if (nlines < 0 || !in_dev) return vps_fail(ctx, VPS_ERR_ARG, "bad line count / null input");
@@ -2111,6 +2153,11 @@ static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz
   if ((1 << p.seg_shift) != p.seglen) p.seg_shift = -1;   // not a power of two: the kernel divides
   p.seg_stride = seg_stride;
   p.tw_stage = tx.tw_stage;
+  if (rows_per_plane && rows_per_plane != N) {
+    if (rows_per_plane < 1 || rows_per_plane > N || !(rows_per_plane & 1) || line0 != 0 || nlines % N || (mode != 0 && mode != 3))
+      return vps_fail(ctx, VPS_ERR_ARG, "packed rows: rows_per_plane=%d must be odd and < N, whole planes from line 0, binning modes only", rows_per_plane);
+    p.rpp = rows_per_plane;
+  }
   if (mode == 0 || mode == 3) {
     if (ctx->bin_N != N || !ctx->d_k2) return vps_fail(ctx, VPS_ERR_ARG, "vps_set_binning(N=%d) has not been called", N);
     if (!psum_dev || (mode == 0 && !nsample_dev)) return vps_fail(ctx, VPS_ERR_ARG, "null accumulator");
@@ -2161,6 +2208,19 @@ int vps_fft_x_bin(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, c
     if (!in_devs[c]) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_x_bin: null component %d", c);
   return fft_x_impl(ctx, N, nlines, line0, kz0, in_devs[0], in_devs[ncomp > 1 ? 1 : 0], in_devs[ncomp > 2 ? 2 : 0],
                     ncomp, nseg, seg_stride, count ? 0 : 3, psum_dev, nsample_dev, nullptr);
+}
+
+// vps_fft_x_bin on the PACKED blocks vps_fft_y writes inside a binning-only scope: rows_per_plane = vps_fft_y_chunk_rows(...)
+// of the chunk (N or 0: not packed), seg_stride = the packed block size, nlines = whole planes (planes * N), line0 = 0.
+int vps_fft_x_bin_rows(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const void* const* in_devs,
+                       int ncomp, int nseg, int64_t seg_stride, int count, int rows_per_plane, double* psum_dev,
+                       unsigned long long* nsample_dev) {
+  VPS_ENTER(ctx);
+  if (ncomp < 1 || ncomp > 3 || !in_devs) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_x_bin_rows: ncomp must be 1..3");
+  for (int c = 0; c < ncomp; ++c)
+    if (!in_devs[c]) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_x_bin_rows: null component %d", c);
+  return fft_x_impl(ctx, N, nlines, line0, kz0, in_devs[0], in_devs[ncomp > 1 ? 1 : 0], in_devs[ncomp > 2 ? 2 : 0],
+                    ncomp, nseg, seg_stride, count ? 0 : 3, psum_dev, nsample_dev, nullptr, rows_per_plane);
 }
 
 int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, double* psum_dev,

@@ -41,6 +41,7 @@ struct vps_ctx {
   // y-pass store cut for binning-only consumers (vps_set_bin_only): kcut[kz] = largest |ky| index whose modes can still reach
   // a shell, rounded up to the x pass's tile granularity; -1: none
   int* d_kcut = nullptr;
+  std::vector<int> h_kcut;   // host copy (row packing of the chunked exchange: vps_fft_y_chunk_rows)
   bool bin_only = false;
 
   // 1 / W(k)^2 per axis index of the mass-assignment window (vps_set_window); NULL: no deconvolution

@@ -11,6 +11,7 @@ class OracleKernels:
 
     def __init__(self):
         self.binning = None
+        self._bin_only = False
 
     def fft_supported(self, N):
         return N >= 4 and (N & (N - 1)) == 0
@@ -47,12 +48,49 @@ class OracleKernels:
         BN = np.ascontiguousarray(Fz[:, :, N // 2]).astype(np.complex64)                        # [x, y]
         return torch.from_numpy(np.concatenate((B.ravel(), BN.ravel())))
 
+    # -- chunk layout of the slab exchange (include/vps_hip.h: vps_fft_y, vps_fft_y_chunk_kz0 / _rows) --
+    def binning_only(self):
+        """Scope in which chunk_rows packs the rows that can still reach a shell (vps_set_bin_only)."""
+        k = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                k._bin_only = True
+
+            def __exit__(self_inner, *exc):
+                k._bin_only = False
+                return False
+        return _Scope()
+
+    def chunk_kz0(self, N, G, nchunks, chunk, rank):
+        nkc = N // 2 // G // nchunks
+        assert nkc * G * nchunks == N // 2
+        return chunk * G * nkc + rank * nkc
+
+    def chunk_rows(self, N, G, nchunks, chunk):
+        if not getattr(self, "_bin_only", False) or self.binning is None or N < 16:
+            return N
+        Nb, k2, thr = self.binning
+        k0, nband = self.chunk_kz0(N, G, nchunks, chunk, 0), N // 2 // nchunks
+        kc = 0
+        for kz in range(k0, k0 + nband):
+            ok = np.nonzero(~((k2[: N // 2 + 1] + k2[kz]) >= thr[-1]))[0]
+            kc = max(kc, int(ok.max()) if ok.size else 0)
+        kc = min(kc | 3, N // 2)          # (the library rounds up to its tile granularity; any kc >= the exact one is valid)
+        return min(2 * kc + 1, N)
+
+    def y_chunk_block(self, N, nx, G, nchunks, chunk, rows):
+        nkc, nky = N // 2 // G // nchunks, N // G
+        return nkc * rows * nx + (nky * nx if chunk == nchunks - 1 else 0)
+
     def fft_y_chunk(self, zimg, N, nx, G, nchunks, chunk, out=None):
-        """vps_fft_y: [h][ F_zy[kz in h's chunk rows][ky][x] | (last chunk) Nyquist rows ky in h's range ]."""
+        """vps_fft_y: [h][ F_zy[kz in h's planes of the chunk][row][x] | (last chunk) Nyquist rows ky in h's range ]."""
         NH = N // 2
-        nkz, nky = NH // G, N // G
-        nkc = nkz // nchunks
-        assert nkc * nchunks == nkz
+        nky = N // G
+        nkc = NH // G // nchunks
+        rows = self.chunk_rows(N, G, nchunks, chunk)
+        kc = (rows - 1) // 2
+        keep = np.arange(N) if rows == N else np.concatenate((np.arange(kc + 1), np.arange(N - kc, N)))
         z = zimg.numpy()
         B = z[: nx * NH * N].reshape(nx, NH, N).astype(np.complex128)
         BN = z[nx * NH * N:].reshape(nx, N).astype(np.complex128)
@@ -60,8 +98,8 @@ class OracleKernels:
         CN = np.fft.fft(BN, axis=1).T                                 # [ky, x]
         parts = []
         for h in range(G):
-            k0 = h * nkz + chunk * nkc
-            parts.append(Cy[k0:k0 + nkc].ravel())
+            k0 = self.chunk_kz0(N, G, nchunks, chunk, h)
+            parts.append(Cy[k0:k0 + nkc][:, keep].ravel())
             if chunk == nchunks - 1:
                 parts.append(CN[h * nky:(h + 1) * nky].ravel())
         return torch.from_numpy(np.concatenate(parts).astype(np.complex64))
@@ -73,8 +111,19 @@ class OracleKernels:
                 for g in range(nseg)]
         return np.concatenate(segs, axis=1)
 
-    def fft_x_bin_multi(self, comps, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True):
+    def fft_x_bin_multi(self, comps, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True, rows=0):
         for i, lines in enumerate(comps):
+            if rows and rows != N:        # packed rows: put them back in place (the missing ones hold nothing that is binned)
+                assert line0 == 0 and nlines % N == 0
+                planes, kc, seglen = nlines // N, (rows - 1) // 2, N // nseg
+                flat = lines.numpy().reshape(-1)
+                full = np.zeros((nseg, planes, N, seglen), dtype=np.complex64)
+                keep = np.concatenate((np.arange(kc + 1), np.arange(N - kc, N)))
+                for g in range(nseg):
+                    full[g][:, keep] = flat[g * seg_stride: g * seg_stride + planes * rows * seglen].reshape(planes, rows, seglen)
+                lines = torch.from_numpy(full.reshape(-1))
+                self.fft_x_bin(lines, N, nlines, 0, kz0, nseg, planes * N * seglen, psum, nsample, count=count and i == 0)
+                continue
             self.fft_x_bin(lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=count and i == 0)
 
     def fft_x_bin(self, lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True):
