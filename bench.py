@@ -358,14 +358,16 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     nchunks = wl.pipe.nchunks
     exchange_rows = None
     if G > 1 and wl.pipe.chunked:
-        # a rank receives nkc planes of every band of G*nkc planes (vps_fft_y_chunk_kz0): the rows it keeps, and the rows per
-        # plane that cross the node (the blocks carry only the rows a plane of the band can still need: vps_fft_y_chunk_rows)
+        # slot j of band c of a rank is plane c*G*nkc + j*G + rank (include/vps_hip.h: vps_fft_y): the rows this rank keeps,
+        # and the share of a block's rows that crosses the node (the blocks leave the rows no shell can reach at home)
         nkc_ = N // 2 // G // nchunks
-        wl_keep = float(np.mean([wl.pipe.kept_row_fraction(c * G * nkc_ + comm.rank * nkc_, c * G * nkc_ + (comm.rank + 1) * nkc_)
-                                 for c in range(nchunks)]))
+        wl_keep = float(np.mean([wl.pipe.kept_row_fraction(p_, p_ + 1)
+                                 for c in range(nchunks) for p_ in range(c * G * nkc_ + comm.rank, (c + 1) * G * nkc_, G)]))
         wl.pipe.prepare()
         with wl.pipe._bin_scope():
-            exchange_rows = float(np.mean([K.chunk_rows(N, G, nchunks, c) for c in range(nchunks)])) / N
+            packed_ = K.y_packed(N)
+        exchange_rows = (sum(K.chunk_block(N, nx, G, nchunks, c, packed_) for c in range(nchunks)) /
+                         float(sum(K.chunk_block(N, nx, G, nchunks, c, False) for c in range(nchunks))))
     elif G > 1:
         wl_keep = wl.pipe.kept_row_fraction(comm.rank * (N // 2 // G), (comm.rank + 1) * (N // 2 // G))
     else:

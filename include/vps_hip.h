@@ -247,18 +247,18 @@ int vps_fft_zy_weighted(vps_ctx* ctx, int N, int nx, const float* field_dev, con
  *   vps_deposit_fft_z  the fused deposit + field algebra + z pass of vps_deposit_fft_zy, stopping there: ncomp z images
  *                      (3: velocity / momentum, 1: energy) in zimg_dev; work_dev: vps_deposit_fft_z_workspace_bytes;
  *   vps_fft_y          y pass of chunk `chunk` of `nchunks` of a z image.  The kz < N/2 planes are cut into nchunks BANDS
- *                      of G*nkc planes (nkc = N/2/G/nchunks); in chunk c rank h receives the nkc planes from
- *                      vps_fft_y_chunk_kz0(N, G, nchunks, c, h) = c*G*nkc + h*nkc on (every rank gets planes of every
- *                      |kz|).  They are transformed and written as ONE send buffer for an equal-split all-to-all,
- *                      out_dev = [h][ F_zy[kz][row][x] (nkc*rows*nx) | -- last chunk only -- Nyquist rows
- *                      F_zy[N/2][ky in rank h's N/G rows][x] (N/G*nx) ], with rows = vps_fft_y_chunk_rows(ctx, N, G,
- *                      nchunks, c): N (row = ky), or, inside a binning-only scope (vps_set_bin_only), the 2 kc + 1 rows
- *                      |ky| <= kc that a plane of the band can still contribute to a shell -- row ky at position ky, row
- *                      N - j at position rows - j -- so the rows nobody bins do not cross the node either.
- *                      vps_fft_y_chunk_elems(...) (rows = N) is an upper bound of the buffer in complex64 elements.  After
- *                      the exchange the buffer received from rank g is that layout with x running over g's slab:
- *                      vps_fft_x_bin_rows reads it with nseg = G, seg_stride = one block, rows_per_plane = rows (and
- *                      vps_fft_x / vps_fft_x_bin the Nyquist lines at offset nkc*rows*nx of the blocks).
+ *                      of G*nkc planes (nkc = N/2/G/nchunks) and dealt out round-robin inside a band: slot j of rank h is
+ *                      plane chunk*G*nkc + j*G + h (every rank gets planes of every |kz|, and the j-th planes of all ranks
+ *                      are neighbours).  They are transformed and written as ONE send buffer for an equal-split all-to-all,
+ *                      out_dev = [h][ slot 0 rows | slot 1 rows | ... | -- last chunk only -- Nyquist rows
+ *                      F_zy[N/2][ky in rank h's N/G rows][x] (N/G*nx) ], each row nx complex64.  A slot holds all N rows of
+ *                      its plane (row = ky), or -- inside a binning-only scope (vps_set_bin_only), vps_fft_y_packed() = 1
+ *                      -- only the 2 kc + 1 rows |ky| <= kc that the slot's planes can still contribute to a shell (row ky
+ *                      at position ky, row N - i at position 2 kc + 1 - i), so the rows nobody bins do not cross the node
+ *                      either.  One destination's block is vps_fft_y_chunk_block(ctx, ..., packed) elements,
+ *                      vps_fft_y_chunk_elems(...) (all rows, all G blocks) an upper bound of the whole buffer.  After the
+ *                      exchange the G blocks a rank received (x running over the senders' slabs) go to
+ *                      vps_fft_x_bin_chunk with the same `packed`.
  * This replaces the four allgathers per buffer flush of scripts/parallel_optimized.py:365-368 with one message per
  * scalar field (or several chunks of it, so that the exchange of one chunk overlaps the passes of its neighbours). */
 size_t vps_fft_zimage_bytes(int N, int nx);
@@ -268,8 +268,8 @@ int vps_deposit_fft_z(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const f
                       const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx,
                       int quantity, int flags, void* zimg_dev, void* work_dev);
 int64_t vps_fft_y_chunk_elems(int N, int nx, int G, int nchunks, int chunk);   /* -1: G, nchunks do not divide */
-int vps_fft_y_chunk_kz0(int N, int G, int nchunks, int chunk, int rank);      /* first kz plane; -1: does not divide */
-int vps_fft_y_chunk_rows(vps_ctx* ctx, int N, int G, int nchunks, int chunk); /* rows per plane in the blocks; -1: bad */
+int vps_fft_y_packed(vps_ctx* ctx, int N);   /* 1: vps_fft_y packs rows now (binning-only scope with a row cut for N) */
+int64_t vps_fft_y_chunk_block(vps_ctx* ctx, int N, int nx, int G, int nchunks, int chunk, int packed);   /* -1: bad */
 int vps_fft_y(vps_ctx* ctx, int N, int nx, const void* zimg_dev, int G, int nchunks, int chunk, void* out_dev);
 
 /* x pass over `nlines` lines of length N.  Line i is made of nseg segments of
@@ -300,13 +300,12 @@ int vps_fft_x(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0,
 int vps_fft_x_bin(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0,
                   const void* const* in_devs, int ncomp, int nseg, int64_t seg_stride, int count,
                   double* psum_dev, unsigned long long* nsample_dev);
-/* The same on the row-PACKED blocks of the chunked exchange (vps_fft_y inside a binning-only scope): whole planes
- * (nlines a multiple of N, line0 = 0) of which only rows_per_plane = vps_fft_y_chunk_rows(...) rows were sent; line
- * (plane, ky) is read from row plane*rows_per_plane + (ky <= kc ? ky : ky - (N - rows_per_plane)), kc = (rows_per_plane-1)/2,
- * rows in between are not there and hold no mode inside the last shell edge.  rows_per_plane = N or 0: vps_fft_x_bin. */
-int vps_fft_x_bin_rows(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0,
-                       const void* const* in_devs, int ncomp, int nseg, int64_t seg_stride, int count,
-                       int rows_per_plane, double* psum_dev, unsigned long long* nsample_dev);
+/* Binning x pass of ONE received chunk of the slab exchange (layout: vps_fft_y): in_devs[c] = the G blocks this rank
+ * received for component c, `packed` what the senders' vps_fft_y_packed() returned; count as in vps_fft_x_bin.  The last
+ * chunk's Nyquist-plane rows are binned by the same call. */
+int vps_fft_x_bin_chunk(vps_ctx* ctx, int N, int nx, int G, int nchunks, int chunk, int rank, int packed,
+                        const void* const* in_devs, int ncomp, int count, double* psum_dev,
+                        unsigned long long* nsample_dev);
 
 /* Single-GPU convenience: full |F(k)|^2 binning of one real field.
  * field_dev [N][N][N] float32 is preserved; work_dev: vps_power_workspace_bytes(N). */

@@ -86,6 +86,7 @@ int vps_destroy(vps_ctx* ctx) {
   if (ctx->d_xpart) (void)hipFree(ctx->d_xpart);
   if (ctx->d_win) (void)hipFree(ctx->d_win);
   if (ctx->d_kcut) (void)hipFree(ctx->d_kcut);
+  if (ctx->ypack.d_tab) (void)hipFree(ctx->ypack.d_tab);
   for (auto& l : ctx->launches) {
     (void)hipEventDestroy(l.start);
     (void)hipEventDestroy(l.stop);
@@ -250,6 +251,7 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
   if (ctx->d_kcut) VPS_HIP_CHECK(ctx, hipFree(ctx->d_kcut));
   ctx->d_kcut = nullptr;
   ctx->h_kcut.clear();
+  ctx->ypack.N = 0;   // (the exchange's plane tables follow the cut: rebuilt on the next use)
   if (fast && N >= 128) {
     std::vector<int> kcut(N / 2 + 1);
     for (int kz = 0; kz <= N / 2; ++kz) {

@@ -503,10 +503,12 @@ struct PassParams {
   // there lies beyond the last shell edge and the binning x pass does not read them.  kz = kz_fixed, or the input batch
   const int* kcut;
   int kz_fixed;
-  // row packing of the chunked exchange (vps_fft_y inside a binning-only scope): every plane of the launch keeps the
-  // 2 kc_pack + 1 rows |ky| <= kc_pack (kc_pack >= every plane's kcut; out_ob is then (2 kc_pack + 1) rows) -- row ky sits at
-  // position ky, row NC - j at position 2 kc_pack + 1 - j.  -1: all NC rows in place.
-  int kc_pack = -1;
+  // chunked exchange (vps_fft_y): ptab[j] = {first row, kc} of the j-th plane of every destination's block (j = launch batch %
+  // bg) -- the plane keeps the 2 kc + 1 rows |ky| <= kc (kc >= its kcut; -1: all NC rows): row ky at position ky, row NC - i at
+  // position 2 kc + 1 - i behind the block's first row.  Launch batch b reads input batch
+  // b_off + (b / bg) * bg_in + (b % bg) * bg_step.  NULL: plain planes of NC rows, out_ob apart.
+  const int2* ptab = nullptr;
+  int bg_step = 1;
 };
 
 __device__ __forceinline__ int packed_row(int k, int NC, int kc_pack) {
@@ -607,7 +609,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
   }
   const int bo = bid / tiles;                 // batch as the output sees it
   const int a0 = (bid % tiles) * T;
-  const long long b = p.bg ? (long long)(bo / p.bg) * p.bg_in + p.b_off + bo % p.bg : bo;   // batch as the input sees it
+  const long long b = p.bg ? (long long)(bo / p.bg) * p.bg_in + p.b_off + (long long)(bo % p.bg) * p.bg_step : bo;   // batch as the input sees it
   const long long ogap = p.bg ? (long long)(bo / p.bg) * p.bg_gap : 0;
 
   if constexpr (PI::TWLDS)
@@ -666,13 +668,15 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L)
   cf* out = reinterpret_cast<cf*>(p.out) + (long long)bo * p.out_ob + ogap + a0;
   if constexpr (!REAL) {
     const int kc = p.kcut ? p.kcut[p.kz_fixed >= 0 ? p.kz_fixed : (int)b] : NC;
+    const int2 pt = p.ptab ? p.ptab[bo % p.bg] : make_int2(0, -1);   // (uniform over the workgroup)
+    out += (long long)pt.x * p.out_ok;
 #pragma unroll 4
     for (int i = 0; i < RL; ++i) {
       const int idx = tid + i * NT;
       const int tt = idx % T, k = idx / T;
       if (a0 + tt < p.A && min(k, NC - k) <= kc) {
         const cf val = buf[tridx<T>(k, tt)];
-        long long o = (long long)packed_row(k, NC, p.kc_pack) * p.out_ok + tt;
+        long long o = (long long)packed_row(k, NC, pt.y) * p.out_ok + tt;
         if constexpr (KG) o += (long long)(k / p.kg) * p.kg_gap;
         if constexpr (NTEMP)
           store_stream(&out[o], val);
@@ -731,7 +735,7 @@ __global__ void __launch_bounds__(TG* L, (NC == 1024 ? 4 : 1))
   auto load_line = [&](cf (&v)[RL], unsigned tile, int who, int first) {
     constexpr int R0 = PI::R0, NB = RL / R0;
     const int bo_ = (int)(tile / tiles), a0_ = (int)(tile % tiles) * T;
-    const long long b_ = p.bg ? (long long)(bo_ / p.bg) * p.bg_in + p.b_off + bo_ % p.bg : bo_;
+    const long long b_ = p.bg ? (long long)(bo_ / p.bg) * p.bg_in + p.b_off + (long long)(bo_ % p.bg) * p.bg_step : bo_;
     const int tl = who / L, ll = who % L;
     const bool live = (a0_ + first + tl) < p.A;
     const cf* src = reinterpret_cast<const cf*>(p.in) + b_ * p.in_sb + (long long)(a0_ + first + tl) * p.in_sa;
@@ -758,7 +762,7 @@ __global__ void __launch_bounds__(TG* L, (NC == 1024 ? 4 : 1))
   for (; tile < ntiles; tile = (ntiles - tile > gridDim.x) ? tile + gridDim.x : ntiles) {
     const int bo = (int)(tile / tiles);                 // batch as the output sees it
     const int a0 = (int)(tile % tiles) * T;
-    const long long b = p.bg ? (long long)(bo / p.bg) * p.bg_in + p.b_off + bo % p.bg : bo;   // batch as the input sees it
+    const long long b = p.bg ? (long long)(bo / p.bg) * p.bg_in + p.b_off + (long long)(bo % p.bg) * p.bg_step : bo;   // batch as the input sees it
     const long long ogap = p.bg ? (long long)(bo / p.bg) * p.bg_gap : 0;
     {
       const int tida = fresh(tid);
@@ -772,7 +776,8 @@ __global__ void __launch_bounds__(TG* L, (NC == 1024 ? 4 : 1))
       fft_from_regs_l<NC, L, WSYNC>(v1, buf + (tidb / L) * PI::PITCH, tw, tidb % L);
     }
 
-    cf* out = reinterpret_cast<cf*>(p.out) + (long long)bo * p.out_ob + ogap + a0;
+    const int2 pt = p.ptab ? p.ptab[bo % p.bg] : make_int2(0, -1);   // (uniform over the workgroup)
+    cf* out = reinterpret_cast<cf*>(p.out) + (long long)bo * p.out_ob + ogap + (long long)pt.x * p.out_ok + a0;
     const int kc = p.kcut ? p.kcut[p.kz_fixed >= 0 ? p.kz_fixed : (int)b] : NC;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -797,7 +802,7 @@ __global__ void __launch_bounds__(TG* L, (NC == 1024 ? 4 : 1))
         const int tt = idx % T, kk = idx / T, k = kk + h * (NC / 2);
         if (a0 + tt < p.A && min(k, NC - k) <= kc) {
           const cf val = buf[tridx<T>(kk, tt)];
-          const long long o = (long long)packed_row(k, NC, p.kc_pack) * p.out_ok + tt;
+          const long long o = (long long)packed_row(k, NC, pt.y) * p.out_ok + tt;
           if constexpr (NTEMP)
             store_stream(&out[o], val);
           else
@@ -1120,8 +1125,9 @@ struct XParams {
   float edge0, inv_spacing;
   double* psum;
   unsigned long long* nsample;
-  int rpp;   // rows per kz plane of a PACKED input (vps_fft_y_chunk_rows; 0: all N rows in place): line (plane, ky) sits at row
-             // plane * rpp + (ky <= kc ? ky : ky - (N - rpp)), kc = (rpp - 1) / 2; rows kc < ky < N - kc do not exist
+  const int2* ptab;   // chunked exchange (vps_fft_x_bin_chunk; NULL otherwise): plane i of the launch starts at row ptab[i].x of a
+                      // block and holds the rows |ky| <= ptab[i].y (-1: all N), see PassParams::ptab; its kz is kz0 + i * kz_step
+  int kz_step;
   int pair;  // FAST path: tiles pair ky with N-ky (needs whole ky ranges: line0, nlines multiples of N)
   double* part_sum;    // [grid][nbins] per-workgroup partial shell sums
   unsigned* part_cnt;  // [grid][nbins] per-workgroup partial shell counts
@@ -1205,7 +1211,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   auto tile_beyond_shells = [&](long long tile) -> bool {
     if constexpr (MODE == 0 && FAST) {
       if (pair) {
-        const int kz = p.kz0 + (int)(p.line0 / NC) + (int)(tile / tiles_per_plane);
+        const int kz = p.kz0 + ((int)(p.line0 / NC) + (int)(tile / tiles_per_plane)) * p.kz_step;
         return (p.k2[tile_q(tile) * TH] + p.k2[kz]) >= p.thr[p.nbins];
       }
     }
@@ -1226,17 +1232,17 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
     }
     live = li < p.nlines && !tile_beyond_shells(tile);
     lrow = li;
-    if (p.rpp) {   // packed rows (chunked exchange; line0 = 0): every mode of a row that was not sent lies beyond the last edge
-      const long long plane = li / NC;
-      const int ky = (int)(li % NC), kcp = (p.rpp - 1) / 2;
-      live = live && (ky <= kcp || ky >= NC - kcp);
-      lrow = plane * p.rpp + (ky <= kcp ? ky : ky - (NC - p.rpp));
+    if (p.ptab) {   // chunked exchange (line0 = 0): every mode of a row that was not sent lies beyond the last shell edge
+      const int ky = (int)(li % NC);
+      const int2 pt = p.ptab[li / NC];
+      live = live && (pt.y < 0 || ky <= pt.y || ky >= NC - pt.y);
+      lrow = pt.x + packed_row(ky, NC, pt.y);
     }
     if constexpr (MODE == 0) {
       if (live) {
         const long long g = p.line0 + li;
         // (lines of the x pass have N = NC points: a compile-time divisor instead of a 64-bit division per tile and thread)
-        const int kz = p.kz0 + (int)(g / NC);
+        const int kz = p.kz0 + (int)(g / NC) * p.kz_step;
         k2y = p.k2[(int)(g % NC)];
         k2z = p.k2[kz];
         wz = (kz == 0 || 2 * kz == NC) ? 1u : 2u;
@@ -1963,26 +1969,62 @@ int64_t vps_fft_y_chunk_elems(int N, int nx, int G, int nchunks, int chunk) {
   return (int64_t)G * (nkc * N * nx + (chunk == nchunks - 1 ? (int64_t)(N / G) * nx : 0));
 }
 
-// Which kz planes a rank receives in chunk `chunk`: the half spectrum is cut into `nchunks` BANDS of G * nkc planes and every
-// rank gets nkc consecutive planes of each band -- so that (a) the planes of one chunk lie close together and can share one
-// row cut (below), and (b) every rank receives planes from all |kz|, i.e. the same share of rows the binning can skip.
-int vps_fft_y_chunk_kz0(int N, int G, int nchunks, int chunk, int rank) {
-  if (G < 1 || nchunks < 1 || N < 2 || (N / 2) % (G * nchunks)) return -1;
-  const int nkc = N / 2 / G / nchunks;
-  return chunk * G * nkc + rank * nkc;
+// ---- layout of the chunked slab exchange --------------------------------------------------------------------------------
+// The kz < N/2 planes are cut into `nchunks` bands of G * nkc planes (nkc = N/2/G/nchunks); inside band c the planes are dealt
+// out round-robin: slot j of rank h is plane c*G*nkc + j*G + h.  So (a) every rank holds planes of every |kz| -- the same
+// share of rows its x passes can skip -- and (b) the j-th planes of all ranks are neighbours in kz and need the same rows to
+// within one step of the cut: packed, every destination's block carries, for slot j, the 2 kc_j + 1 rows |ky| <= kc_j with
+// kc_j = the largest kcut of the G planes of slot j.  Equal blocks for all destinations, a table of nkc entries per chunk.
+static bool ypack_wanted(const vps_ctx* ctx, int N) {
+  return ctx->bin_only && ctx->bin_N == N && (int)ctx->h_kcut.size() == N / 2 + 1;
 }
 
-// Rows per kz plane in the send / receive blocks of chunk `chunk`: N, or -- inside a binning-only scope (vps_set_bin_only)
-// with tables that have a row cut -- the 2 kc + 1 rows |ky| <= kc that any plane of the chunk's band can still need.
-int vps_fft_y_chunk_rows(vps_ctx* ctx, int N, int G, int nchunks, int chunk) {
-  if (!ctx) return -1;
-  const int k0 = vps_fft_y_chunk_kz0(N, G, nchunks, chunk, 0);
-  if (k0 < 0) return -1;
-  if (!(ctx->bin_only && ctx->bin_N == N && (int)ctx->h_kcut.size() == N / 2 + 1)) return N;
-  const int nband = N / 2 / nchunks;
-  int kc = 0;
-  for (int kz = k0; kz < k0 + nband; ++kz) kc = ctx->h_kcut[kz] > kc ? ctx->h_kcut[kz] : kc;
-  return 2 * kc + 1 < N ? 2 * kc + 1 : N;
+// plane table of chunk `chunk` (device) and the rows of one destination's block; (re)built for (N, G, nchunks, packed)
+static int ypack_get(vps_ctx* ctx, int N, int G, int nchunks, int chunk, bool packed, const int2** tab, long long* rows) {
+  if (G < 1 || nchunks < 1 || N < 2 || (N / 2) % (G * nchunks) || chunk < 0 || chunk >= nchunks)
+    return vps_fail(ctx, VPS_ERR_ARG, "chunked exchange: G=%d ranks x %d chunks must divide N/2=%d", G, nchunks, N / 2);
+  if (packed && (int)ctx->h_kcut.size() != N / 2 + 1)
+    return vps_fail(ctx, VPS_ERR_ARG, "chunked exchange: packed rows need the row cut of vps_set_binning(N=%d)", N);
+  const int nkc = N / 2 / G / nchunks;
+  auto& y = ctx->ypack;
+  if (!(y.N == N && y.G == G && y.C == nchunks && y.packed == (int)packed && y.d_tab)) {
+    std::vector<int2> t((size_t)nchunks * nkc);
+    y.rows.assign(nchunks, 0);
+    for (int c = 0; c < nchunks; ++c) {
+      long long r = 0;
+      for (int j = 0; j < nkc; ++j) {
+        int kc = -1;
+        if (packed) {
+          kc = 0;
+          for (int h = 0; h < G; ++h) kc = std::max(kc, ctx->h_kcut[c * G * nkc + j * G + h]);
+          if (2 * kc + 1 >= N) kc = -1;
+        }
+        t[(size_t)c * nkc + j] = make_int2((int)r, kc);
+        r += kc < 0 ? N : 2 * kc + 1;
+      }
+      y.rows[c] = r;
+    }
+    VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // (a launch may still read the old table)
+    if (y.d_tab) VPS_HIP_CHECK(ctx, hipFree(y.d_tab));
+    y.d_tab = nullptr;
+    y.N = 0;
+    VPS_HIP_CHECK(ctx, hipMalloc(&y.d_tab, t.size() * sizeof(int2)));
+    VPS_HIP_CHECK(ctx, hipMemcpy(y.d_tab, t.data(), t.size() * sizeof(int2), hipMemcpyHostToDevice));
+    y.N = N; y.G = G; y.C = nchunks; y.packed = (int)packed;
+  }
+  if (tab) *tab = reinterpret_cast<const int2*>(y.d_tab) + (size_t)chunk * nkc;
+  if (rows) *rows = y.rows[chunk];
+  return VPS_OK;
+}
+
+int vps_fft_y_packed(vps_ctx* ctx, int N) { return ctx && ypack_wanted(ctx, N) ? 1 : 0; }
+
+int64_t vps_fft_y_chunk_block(vps_ctx* ctx, int N, int nx, int G, int nchunks, int chunk, int packed) {
+  if (!ctx || nx < 1) return -1;
+  vps_device_guard guard(ctx);
+  long long rows = 0;
+  if (ypack_get(ctx, N, G, nchunks, chunk, packed != 0, nullptr, &rows)) return -1;
+  return rows * nx + (chunk == nchunks - 1 ? (long long)(N / G) * nx : 0);
 }
 
 int vps_fft_y(vps_ctx* ctx, int N, int nx, const void* zimg_dev, int G, int nchunks, int chunk, void* out_dev) {
@@ -1998,33 +2040,37 @@ int vps_fft_y(vps_ctx* ctx, int N, int nx, const void* zimg_dev, int G, int nchu
   if (rc) return rc;
   const cf* B = reinterpret_cast<const cf*>(zimg_dev);
   const cf* BN = B + (size_t)nx * NH * N;
-  const int rows = vps_fft_y_chunk_rows(ctx, N, G, nchunks, chunk);                    // rows per plane (N: not packed)
-  const long long blk = (long long)nkc * rows * nx + (last ? (long long)nky * nx : 0);   // one destination's block
+  const int2* tab = nullptr;
+  long long rows = 0;   // rows of one destination's block (N per plane when not packed)
+  rc = ypack_get(ctx, N, G, nchunks, chunk, ypack_wanted(ctx, N), &tab, &rows);
+  if (rc) return rc;
+  const long long blk = rows * nx + (last ? (long long)nky * nx : 0);   // one destination's block
   (void)nkz;
-  // kz planes {chunk G nkc + h nkc + j} (vps_fft_y_chunk_kz0): launch batch b = h nkc + j reads input batch chunk G nkc + b
+  // launch batch b = h nkc + j (destination h, slot j) reads plane chunk G nkc + j G + h and writes the rows of slot j
   PassParams py{};
   py.in = B;
   py.out = out_dev;
   py.in_sa = (long long)NH * N;
   py.in_sb = N;
-  py.out_ob = (long long)rows * nx;
+  py.out_ob = 0;
   py.out_ok = nx;
   py.A = nx;
   py.B = G * nkc;
   py.tw_stage = ty.tw_stage;
   py.bg = nkc;
   py.b_off = chunk * G * nkc;
-  py.bg_in = nkc;
-  py.bg_gap = last ? (long long)nky * nx : 0;
+  py.bg_in = 1;
+  py.bg_step = G;
+  py.bg_gap = blk;
+  py.ptab = tab;
   py.kcut = (ctx->bin_only && ctx->bin_N == N) ? ctx->d_kcut : nullptr;
   py.kz_fixed = -1;
-  py.kc_pack = rows < N ? (rows - 1) / 2 : -1;
   rc = route_transpose(ctx, N, 0, py, VPS_K_FFT_Y);
   if (rc || !last) return rc;
   // Nyquist plane: ky rows of destination h go behind that destination's kz rows
   PassParams pn{};
   pn.in = BN;
-  pn.out = reinterpret_cast<cf*>(out_dev) + (long long)nkc * rows * nx;
+  pn.out = reinterpret_cast<cf*>(out_dev) + rows * nx;
   pn.in_sa = N;
   pn.in_sb = 0;
   pn.out_ob = 0;
@@ -2128,7 +2174,8 @@ extern "C" {
 
 static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const void* in_dev,
                       const void* in1_dev, const void* in2_dev, int ncomp, int nseg, int64_t seg_stride,
-                      int mode, double* psum_dev, unsigned long long* nsample_dev, void* out_dev, int rows_per_plane = 0) {
+                      int mode, double* psum_dev, unsigned long long* nsample_dev, void* out_dev,
+                      const int2* ptab = nullptr, int kz_step = 1) {
   VPS_ENTER(ctx);
   if (!vps_fft_supported(N)) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "N=%d: need a power of two in [16,4096], 96, 192, 384, 768, 1536, 250, 500, 1000 or 2000", N);
   if (nlines < 0 || !in_dev) return vps_fail(ctx, VPS_ERR_ARG, "bad line count / null input");
@@ -2153,16 +2200,15 @@ static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz
   if ((1 << p.seg_shift) != p.seglen) p.seg_shift = -1;   // not a power of two: the kernel divides
   p.seg_stride = seg_stride;
   p.tw_stage = tx.tw_stage;
-  if (rows_per_plane && rows_per_plane != N) {
-    if (rows_per_plane < 1 || rows_per_plane > N || !(rows_per_plane & 1) || line0 != 0 || nlines % N || (mode != 0 && mode != 3))
-      return vps_fail(ctx, VPS_ERR_ARG, "packed rows: rows_per_plane=%d must be odd and < N, whole planes from line 0, binning modes only", rows_per_plane);
-    p.rpp = rows_per_plane;
-  }
+  p.ptab = ptab;
+  p.kz_step = kz_step;
+  if (ptab && (line0 != 0 || nlines % N || (mode != 0 && mode != 3)))
+    return vps_fail(ctx, VPS_ERR_ARG, "chunk planes: whole planes from line 0, binning modes only");
   if (mode == 0 || mode == 3) {
     if (ctx->bin_N != N || !ctx->d_k2) return vps_fail(ctx, VPS_ERR_ARG, "vps_set_binning(N=%d) has not been called", N);
     if (!psum_dev || (mode == 0 && !nsample_dev)) return vps_fail(ctx, VPS_ERR_ARG, "null accumulator");
     const long long maxline = line0 + nlines - 1;
-    if (kz0 + (int)(maxline / N) > N / 2) return vps_fail(ctx, VPS_ERR_ARG, "kz range exceeds N/2");
+    if (kz0 + (int)(maxline / N) * kz_step > N / 2) return vps_fail(ctx, VPS_ERR_ARG, "kz range exceeds N/2");
     p.k2 = ctx->d_k2;
     p.thr = ctx->d_thr;
     if (ctx->d_win && ctx->win_N != N) return vps_fail(ctx, VPS_ERR_ARG, "vps_set_window was called for N=%d, not %d", ctx->win_N, N);
@@ -2210,17 +2256,32 @@ int vps_fft_x_bin(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, c
                     ncomp, nseg, seg_stride, count ? 0 : 3, psum_dev, nsample_dev, nullptr);
 }
 
-// vps_fft_x_bin on the PACKED blocks vps_fft_y writes inside a binning-only scope: rows_per_plane = vps_fft_y_chunk_rows(...)
-// of the chunk (N or 0: not packed), seg_stride = the packed block size, nlines = whole planes (planes * N), line0 = 0.
-int vps_fft_x_bin_rows(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz0, const void* const* in_devs,
-                       int ncomp, int nseg, int64_t seg_stride, int count, int rows_per_plane, double* psum_dev,
-                       unsigned long long* nsample_dev) {
+// Binning x pass of ONE received chunk of the slab exchange: in_devs[c] = the G blocks this rank received for component c
+// (vps_fft_y's layout, x running over the senders' slabs), `packed` as the senders' vps_fft_y_packed said.  Planes of slot j
+// are kz = chunk*G*nkc + j*G + rank; the last chunk's blocks end with this rank's Nyquist-plane rows, binned here too.
+int vps_fft_x_bin_chunk(vps_ctx* ctx, int N, int nx, int G, int nchunks, int chunk, int rank, int packed,
+                        const void* const* in_devs, int ncomp, int count, double* psum_dev,
+                        unsigned long long* nsample_dev) {
   VPS_ENTER(ctx);
-  if (ncomp < 1 || ncomp > 3 || !in_devs) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_x_bin_rows: ncomp must be 1..3");
+  if (ncomp < 1 || ncomp > 3 || !in_devs) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_x_bin_chunk: ncomp must be 1..3");
   for (int c = 0; c < ncomp; ++c)
-    if (!in_devs[c]) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_x_bin_rows: null component %d", c);
-  return fft_x_impl(ctx, N, nlines, line0, kz0, in_devs[0], in_devs[ncomp > 1 ? 1 : 0], in_devs[ncomp > 2 ? 2 : 0],
-                    ncomp, nseg, seg_stride, count ? 0 : 3, psum_dev, nsample_dev, nullptr, rows_per_plane);
+    if (!in_devs[c]) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_x_bin_chunk: null component %d", c);
+  if (nx < 1 || nx * G != N || rank < 0 || rank >= G) return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_x_bin_chunk: nx * G must be N, 0 <= rank < G");
+  const int2* tab = nullptr;
+  long long rows = 0;
+  int rc = ypack_get(ctx, N, G, nchunks, chunk, packed != 0, &tab, &rows);
+  if (rc) return rc;
+  const int nkc = N / 2 / G / nchunks, nky = N / G;
+  const bool last = chunk == nchunks - 1;
+  const long long blk = rows * nx + (last ? (long long)nky * nx : 0);
+  const int mode = count ? 0 : 3;
+  rc = fft_x_impl(ctx, N, (int64_t)nkc * N, 0, chunk * G * nkc + rank, in_devs[0], in_devs[ncomp > 1 ? 1 : 0],
+                  in_devs[ncomp > 2 ? 2 : 0], ncomp, G, blk, mode, psum_dev, nsample_dev, nullptr, tab, G);
+  if (rc || !last) return rc;
+  const cf* nq[3];
+  for (int c = 0; c < 3; ++c) nq[c] = reinterpret_cast<const cf*>(in_devs[c < ncomp ? c : 0]) + rows * nx;
+  return fft_x_impl(ctx, N, nky, (int64_t)rank * nky, N / 2, nq[0], nq[1], nq[2], ncomp, G, blk, mode, psum_dev, nsample_dev,
+                    nullptr);
 }
 
 int vps_power_bin(vps_ctx* ctx, int N, const float* field_dev, void* work_dev, double* psum_dev,

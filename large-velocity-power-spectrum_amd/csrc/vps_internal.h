@@ -41,7 +41,14 @@ struct vps_ctx {
   // y-pass store cut for binning-only consumers (vps_set_bin_only): kcut[kz] = largest |ky| index whose modes can still reach
   // a shell, rounded up to the x pass's tile granularity; -1: none
   int* d_kcut = nullptr;
-  std::vector<int> h_kcut;   // host copy (row packing of the chunked exchange: vps_fft_y_chunk_rows)
+  std::vector<int> h_kcut;   // host copy (row packing of the chunked exchange)
+  // plane tables of the chunked exchange for one (N, G, nchunks, packed): per chunk and plane slot j {first row, kc} (int2 on
+  // the device) and the rows per destination block of every chunk; rebuilt on demand, dropped by vps_set_binning
+  struct {
+    int N = 0, G = 0, C = 0, packed = -1;
+    void* d_tab = nullptr;
+    std::vector<long long> rows;
+  } ypack;
   bool bin_only = false;
 
   // 1 / W(k)^2 per axis index of the mass-assignment window (vps_set_window); NULL: no deconvolution

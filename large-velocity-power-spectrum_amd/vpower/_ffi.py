@@ -73,14 +73,14 @@ SYMBOLS = (
     ("vps_deposit_fft_z", C.c_int, (_vp, _vp, C.c_int, _vp, _vp, _i64, C.c_int, C.c_double, C.c_int, C.c_int,
                                     C.c_int, C.c_int, _vp, _vp)),
     ("vps_fft_y_chunk_elems", _i64, (C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)),
-    ("vps_fft_y_chunk_kz0", C.c_int, (C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)),
-    ("vps_fft_y_chunk_rows", C.c_int, (_vp, C.c_int, C.c_int, C.c_int, C.c_int)),
+    ("vps_fft_y_packed", C.c_int, (_vp, C.c_int)),
+    ("vps_fft_y_chunk_block", _i64, (_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)),
     ("vps_fft_y", C.c_int, (_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp)),
     ("vps_fft_x", C.c_int, (_vp, C.c_int, _i64, _i64, C.c_int, _vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp)),
     ("vps_fft_x_bin", C.c_int, (_vp, C.c_int, _i64, _i64, C.c_int, C.POINTER(_vp), C.c_int, C.c_int, _i64, C.c_int,
                                _vp, _vp)),
-    ("vps_fft_x_bin_rows", C.c_int, (_vp, C.c_int, _i64, _i64, C.c_int, C.POINTER(_vp), C.c_int, C.c_int, _i64, C.c_int,
-                                    C.c_int, _vp, _vp)),
+    ("vps_fft_x_bin_chunk", C.c_int, (_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp),
+                                     C.c_int, C.c_int, _vp, _vp)),
     ("vps_power_workspace_bytes", C.c_size_t, (C.c_int,)),
     ("vps_power_bin", C.c_int, (_vp, C.c_int, _vp, _vp, _vp, _vp)),
     ("vps_rfft3", C.c_int, (_vp, C.c_int, _vp, _vp, _vp)),

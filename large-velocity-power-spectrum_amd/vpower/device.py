@@ -471,31 +471,23 @@ class HipKernels:
             raise _ffi.VpsError("%d ranks x %d chunks do not divide N/2 = %d" % (G, nchunks, N // 2))
         return n
 
-    def chunk_kz0(self, N, G, nchunks, chunk, rank):
-        """First kz plane rank `rank` receives in chunk `chunk` (bands of G*nkc planes, nkc to every rank)."""
-        k0 = int(self.lib.vps_fft_y_chunk_kz0(int(N), int(G), int(nchunks), int(chunk), int(rank)))
-        if k0 < 0:
-            raise _ffi.VpsError("%d ranks x %d chunks do not divide N/2 = %d" % (G, nchunks, N // 2))
-        return k0
+    def y_packed(self, N):
+        """True when fft_y_chunk packs rows now: inside a `binning_only` scope whose tables have a row cut for N."""
+        return bool(self.lib.vps_fft_y_packed(self.ctx, int(N)))
 
-    def chunk_rows(self, N, G, nchunks, chunk):
-        """Rows per kz plane in the blocks of chunk `chunk`: N, or fewer inside a `binning_only` scope (packed rows)."""
-        r = int(self.lib.vps_fft_y_chunk_rows(self.ctx, int(N), int(G), int(nchunks), int(chunk)))
-        if r < 1:
+    def chunk_block(self, N, nx, G, nchunks, chunk, packed):
+        """Elements of ONE destination's block of chunk `chunk` (include/vps_hip.h: vps_fft_y)."""
+        n = int(self.lib.vps_fft_y_chunk_block(self.ctx, int(N), int(nx), int(G), int(nchunks), int(chunk), int(bool(packed))))
+        if n < 0:
             raise _ffi.VpsError("%d ranks x %d chunks do not divide N/2 = %d" % (G, nchunks, N // 2))
-        return r
-
-    def y_chunk_block(self, N, nx, G, nchunks, chunk, rows):
-        """Elements of ONE destination's block of chunk `chunk` with `rows` rows per plane."""
-        nkc, nky = N // 2 // G // nchunks, N // G
-        return nkc * rows * nx + (nky * nx if chunk == nchunks - 1 else 0)
+        return n
 
     def fft_y_chunk(self, zimg, N, nx, G, nchunks, chunk, out=None):
         """y pass of one kz chunk of a z image -> the send buffer of an equal-split all-to-all over G ranks:
         [h][ F_zy[kz in h's planes of the chunk][row][x] | (last chunk) Nyquist rows of h ] (flat complex64),
-        chunk_rows(...) rows per plane (call it in the same scope)."""
+        G * chunk_block(..., packed=y_packed(N)) elements (ask in the same scope)."""
         self._stream()
-        n = G * self.y_chunk_block(N, nx, G, nchunks, chunk, self.chunk_rows(N, G, nchunks, chunk))
+        n = G * self.chunk_block(N, nx, G, nchunks, chunk, self.y_packed(N))
         if out is None:
             out = self.empty((n,), torch.complex64)
         self._chk(self.lib.vps_fft_y(self.ctx, N, nx, self._ptr(zimg, torch.complex64), G, nchunks, chunk,
@@ -509,19 +501,22 @@ class HipKernels:
                                      seg_stride, 0 if count else 3, self._ptr(psum, torch.float64),
                                      self._ptr(nsample, torch.int64), None))
 
-    def fft_x_bin_multi(self, comps, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True, rows=0):
-        """x pass of up to three component spectra, |F|^2 summed over the components, binned once.
-        rows: rows per plane of row-packed blocks (chunk_rows; 0 or N: all rows in place)."""
+    def fft_x_bin_multi(self, comps, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True):
+        """x pass of up to three component spectra, |F|^2 summed over the components, binned once."""
         self._stream()
         ptrs = (C.c_void_p * len(comps))(*[self._ptr(c, torch.complex64).value for c in comps])
-        if rows and rows != N:
-            self._chk(self.lib.vps_fft_x_bin_rows(self.ctx, N, nlines, line0, kz0, ptrs, len(comps), nseg, seg_stride,
-                                                  1 if count else 0, int(rows), self._ptr(psum, torch.float64),
-                                                  self._ptr(nsample, torch.int64)))
-            return
         self._chk(self.lib.vps_fft_x_bin(self.ctx, N, nlines, line0, kz0, ptrs, len(comps), nseg, seg_stride,
                                          1 if count else 0, self._ptr(psum, torch.float64),
                                          self._ptr(nsample, torch.int64)))
+
+    def fft_x_bin_chunk(self, comps, N, nx, G, nchunks, chunk, rank, packed, psum, nsample, count=True):
+        """Binning x pass of one RECEIVED chunk of the slab exchange (the G blocks per component, fft_y_chunk's layout; the
+        last chunk's Nyquist-plane rows included), up to three components summed before the shell search."""
+        self._stream()
+        ptrs = (C.c_void_p * len(comps))(*[self._ptr(c, torch.complex64).value for c in comps])
+        self._chk(self.lib.vps_fft_x_bin_chunk(self.ctx, int(N), int(nx), int(G), int(nchunks), int(chunk), int(rank),
+                                               int(bool(packed)), ptrs, len(comps), 1 if count else 0,
+                                               self._ptr(psum, torch.float64), self._ptr(nsample, torch.int64)))
 
     def fft_x_write(self, lines, N, nlines, nseg, seg_stride, out):
         self._stream()
@@ -747,7 +742,7 @@ class PowerPipeline:
         started = []
         self.prepare()
         with self._bin_scope():
-            self._chunk_rows = [k.chunk_rows(N, G, C_, c) for c in range(C_)]   # rows per plane of every chunk's blocks
+            self._packed = k.y_packed(N) if hasattr(k, "y_packed") else False   # the blocks carry only the rows a shell can reach
             for i in range(0, len(zimgs), group):
                 comps = zimgs[i:i + group]
                 started.append([[self.comm.all_to_all_start(k.fft_y_chunk(z, N, nx, G, C_, c)) for z in comps]
@@ -771,14 +766,7 @@ class PowerPipeline:
             for c in range(C_):
                 recvs = [self.comm.all_to_all_finish(h) for h in pending[c]]
                 pending[c] = None
-                last = c == C_ - 1
-                rows = self._chunk_rows[c]
-                blk = k.y_chunk_block(N, nx, G, C_, c, rows)
-                k.fft_x_bin_multi(recvs, N, nkc * N, 0, k.chunk_kz0(N, G, C_, c, r), G, blk, psum, nsample, count=cnt,
-                                  rows=rows)
-                if last:
-                    nyqs = [t[nkc * rows * nx:] for t in recvs]
-                    k.fft_x_bin_multi(nyqs, N, nky, r * nky, N // 2, G, blk, psum, nsample, count=cnt)
+                k.fft_x_bin_chunk(recvs, N, nx, G, C_, c, r, self._packed, psum, nsample, count=cnt)
         return psum, nsample
 
     def accumulate_zimages(self, zimgs, psum=None, nsample=None, count=True):

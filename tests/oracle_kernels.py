@@ -48,9 +48,9 @@ class OracleKernels:
         BN = np.ascontiguousarray(Fz[:, :, N // 2]).astype(np.complex64)                        # [x, y]
         return torch.from_numpy(np.concatenate((B.ravel(), BN.ravel())))
 
-    # -- chunk layout of the slab exchange (include/vps_hip.h: vps_fft_y, vps_fft_y_chunk_kz0 / _rows) --
+    # -- chunk layout of the slab exchange (include/vps_hip.h: vps_fft_y, vps_fft_y_chunk_block, vps_fft_x_bin_chunk) --
     def binning_only(self):
-        """Scope in which chunk_rows packs the rows that can still reach a shell (vps_set_bin_only)."""
+        """Scope in which fft_y_chunk packs the rows that can still reach a shell (vps_set_bin_only)."""
         k = self
 
         class _Scope:
@@ -62,35 +62,43 @@ class OracleKernels:
                 return False
         return _Scope()
 
-    def chunk_kz0(self, N, G, nchunks, chunk, rank):
+    def y_packed(self, N):
+        return bool(self._bin_only and self.binning is not None and N >= 16)
+
+    def _slots(self, N, G, nchunks, chunk, packed):
+        """Per slot j of the chunk: (kc, rows) -- the rows |ky| <= kc that the slot's G planes chunk*G*nkc + j*G + h can still
+        contribute to a shell (kc = -1: all N rows).  Any kc >= the exact cut is valid; the library rounds up to 16."""
         nkc = N // 2 // G // nchunks
         assert nkc * G * nchunks == N // 2
-        return chunk * G * nkc + rank * nkc
+        out = []
+        for j in range(nkc):
+            kc = -1
+            if packed:
+                Nb, k2, thr = self.binning
+                kc = 0
+                for h in range(G):
+                    ok = np.nonzero(~((k2[: N // 2 + 1] + k2[chunk * G * nkc + j * G + h]) >= thr[-1]))[0]
+                    kc = max(kc, int(ok.max()) if ok.size else 0)
+                kc = min(kc | 3, N // 2)
+                if 2 * kc + 1 >= N:
+                    kc = -1
+            out.append((kc, N if kc < 0 else 2 * kc + 1))
+        return out
 
-    def chunk_rows(self, N, G, nchunks, chunk):
-        if not getattr(self, "_bin_only", False) or self.binning is None or N < 16:
-            return N
-        Nb, k2, thr = self.binning
-        k0, nband = self.chunk_kz0(N, G, nchunks, chunk, 0), N // 2 // nchunks
-        kc = 0
-        for kz in range(k0, k0 + nband):
-            ok = np.nonzero(~((k2[: N // 2 + 1] + k2[kz]) >= thr[-1]))[0]
-            kc = max(kc, int(ok.max()) if ok.size else 0)
-        kc = min(kc | 3, N // 2)          # (the library rounds up to its tile granularity; any kc >= the exact one is valid)
-        return min(2 * kc + 1, N)
+    @staticmethod
+    def _keep(N, kc):
+        return np.arange(N) if kc < 0 else np.concatenate((np.arange(kc + 1), np.arange(N - kc, N)))
 
-    def y_chunk_block(self, N, nx, G, nchunks, chunk, rows):
-        nkc, nky = N // 2 // G // nchunks, N // G
-        return nkc * rows * nx + (nky * nx if chunk == nchunks - 1 else 0)
+    def chunk_block(self, N, nx, G, nchunks, chunk, packed):
+        rows = sum(r for _, r in self._slots(N, G, nchunks, chunk, packed))
+        return rows * nx + (N // G * nx if chunk == nchunks - 1 else 0)
 
     def fft_y_chunk(self, zimg, N, nx, G, nchunks, chunk, out=None):
-        """vps_fft_y: [h][ F_zy[kz in h's planes of the chunk][row][x] | (last chunk) Nyquist rows ky in h's range ]."""
+        """vps_fft_y: [h][ slot 0 rows | slot 1 rows | ... | (last chunk) Nyquist rows ky in h's range ]."""
         NH = N // 2
         nky = N // G
         nkc = NH // G // nchunks
-        rows = self.chunk_rows(N, G, nchunks, chunk)
-        kc = (rows - 1) // 2
-        keep = np.arange(N) if rows == N else np.concatenate((np.arange(kc + 1), np.arange(N - kc, N)))
+        slots = self._slots(N, G, nchunks, chunk, self.y_packed(N))
         z = zimg.numpy()
         B = z[: nx * NH * N].reshape(nx, NH, N).astype(np.complex128)
         BN = z[nx * NH * N:].reshape(nx, N).astype(np.complex128)
@@ -98,11 +106,34 @@ class OracleKernels:
         CN = np.fft.fft(BN, axis=1).T                                 # [ky, x]
         parts = []
         for h in range(G):
-            k0 = self.chunk_kz0(N, G, nchunks, chunk, h)
-            parts.append(Cy[k0:k0 + nkc][:, keep].ravel())
+            for j, (kc, _) in enumerate(slots):
+                parts.append(Cy[chunk * G * nkc + j * G + h][self._keep(N, kc)].ravel())
             if chunk == nchunks - 1:
                 parts.append(CN[h * nky:(h + 1) * nky].ravel())
         return torch.from_numpy(np.concatenate(parts).astype(np.complex64))
+
+    def fft_x_bin_chunk(self, comps, N, nx, G, nchunks, chunk, rank, packed, psum, nsample, count=True):
+        """vps_fft_x_bin_chunk: the G received blocks per component -> planes in place, binned plane by plane (+ Nyquist rows)."""
+        nkc, nky = N // 2 // G // nchunks, N // G
+        slots = self._slots(N, G, nchunks, chunk, packed)
+        blk = self.chunk_block(N, nx, G, nchunks, chunk, packed)
+        rows_total = sum(r for _, r in slots)
+        for i, lines in enumerate(comps):
+            flat = lines.numpy().reshape(-1)
+            assert flat.size == G * blk
+            r0 = 0
+            for j, (kc, rows) in enumerate(slots):
+                plane = np.zeros((N, N), dtype=np.complex64)          # [ky][x]; rows that were not sent hold nothing binned
+                keep = self._keep(N, kc)
+                for g in range(G):
+                    plane[keep, g * nx:(g + 1) * nx] = flat[g * blk + r0 * nx: g * blk + (r0 + rows) * nx].reshape(rows, nx)
+                self.fft_x_bin(torch.from_numpy(plane.reshape(-1)), N, N, 0, chunk * G * nkc + j * G + rank, 1, N * N, psum, nsample,
+                               count=count and i == 0)
+                r0 += rows
+            if chunk == nchunks - 1:
+                nyq = np.concatenate([flat[g * blk + rows_total * nx: (g + 1) * blk].reshape(nky, nx) for g in range(G)], axis=1)
+                self.fft_x_bin(torch.from_numpy(np.ascontiguousarray(nyq).reshape(-1)), N, nky, rank * nky, N // 2, 1, nky * N, psum,
+                               nsample, count=count and i == 0)
 
     def _lines(self, lines, N, nlines, nseg, seg_stride):
         flat = lines.numpy().reshape(-1)
@@ -111,19 +142,8 @@ class OracleKernels:
                 for g in range(nseg)]
         return np.concatenate(segs, axis=1)
 
-    def fft_x_bin_multi(self, comps, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True, rows=0):
+    def fft_x_bin_multi(self, comps, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True):
         for i, lines in enumerate(comps):
-            if rows and rows != N:        # packed rows: put them back in place (the missing ones hold nothing that is binned)
-                assert line0 == 0 and nlines % N == 0
-                planes, kc, seglen = nlines // N, (rows - 1) // 2, N // nseg
-                flat = lines.numpy().reshape(-1)
-                full = np.zeros((nseg, planes, N, seglen), dtype=np.complex64)
-                keep = np.concatenate((np.arange(kc + 1), np.arange(N - kc, N)))
-                for g in range(nseg):
-                    full[g][:, keep] = flat[g * seg_stride: g * seg_stride + planes * rows * seglen].reshape(planes, rows, seglen)
-                lines = torch.from_numpy(full.reshape(-1))
-                self.fft_x_bin(lines, N, nlines, 0, kz0, nseg, planes * N * seglen, psum, nsample, count=count and i == 0)
-                continue
             self.fft_x_bin(lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=count and i == 0)
 
     def fft_x_bin(self, lines, N, nlines, line0, kz0, nseg, seg_stride, psum, nsample, count=True):
