@@ -201,18 +201,20 @@ class Workload:
         K, dev, N, L, nx, x0 = self.K, self.dev, self.N, self.L, self.nx, self.x0
         out = {}
         if self.route == "ngp" and getattr(self, "pipelined", False):
-            token, prev = None, None
-            for i, q in enumerate(self.quantities):
-                ps, ns = self.acc_q[i]
+            state = {"token": None}
+
+            def producer(i, q):
+                def produce():
+                    z = K.deposit_fft_z(self.pos, self.vel, self.rho, N, L, x0, nx, dev.QUANTITY[q], zimg=self.zimg_q[i],
+                                        reuse_sort=state["token"])
+                    state["token"] = K.fused_token()
+                    return [z[c] for c in range(NCOMP[q])]
+                return produce
+            for ps, ns in self.acc_q:
                 ps.zero_()
                 ns.zero_()
-                z = K.deposit_fft_z(self.pos, self.vel, self.rho, N, L, x0, nx, dev.QUANTITY[q], zimg=self.zimg_q[i], reuse_sort=token)
-                token = K.fused_token()
-                started = self.pipe.start_zimages([z[c] for c in range(NCOMP[q])])
-                if prev is not None:                       # bin the previous quantity while this one's chunks travel
-                    self.pipe.finish_zimages(prev[1], *self.acc_q[prev[0]])
-                prev = (i, started)
-            self.pipe.finish_zimages(prev[1], *self.acc_q[prev[0]])
+            # quantity q+1's deposit + z pass + y passes are issued while q's chunks cross the node (PowerPipeline.pipelined_quantities)
+            self.pipe.pipelined_quantities([producer(i, q) for i, q in enumerate(self.quantities)], self.acc_q)
             for i, q in enumerate(self.quantities):
                 tab = self.pipe.finish(*self.acc_q[i])
                 tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2

@@ -57,7 +57,14 @@ int vps_destroy(vps_ctx* ctx);
 const char* vps_last_error(const vps_ctx* ctx);   /* ctx may be NULL: global slot */
 int vps_set_stream(vps_ctx* ctx, void* hip_stream);
 int vps_sync(vps_ctx* ctx);
-int vps_version(void);                            /* ABI version, currently 2       */
+int vps_version(void);                            /* ABI version, currently 3       */
+/* Tuning / test switches, process-wide.  The library never reads the environment: a stray variable in a user's job cannot
+ * change a code path; the host sets what it wants explicitly (vpower/_ffi.py maps VPS_OPT_<NAME> variables once, at load,
+ * and lists them in _ffi.OPTIONS).  Names: no_fast_binning, no_pair_binning, nn_query_centric, nn_kappa, nn_stats,
+ * sort_groups, sort_staged, sort_atomic (all result-preserving), nn_ablate (timing-only builds; ignored by the product
+ * build).  A NaN value restores the default.  Unknown names: VPS_ERR_ARG. */
+int vps_set_option(const char* name, double value);
+double vps_get_option(const char* name, double dflt);
 /* device facts for the host side: out[0]=CUs, out[1]=LDS bytes/CU, out[2]=wave size,
  * out[3]=HBM bytes total (MiB) */
 int vps_device_info(vps_ctx* ctx, int64_t out[4]);
@@ -269,7 +276,7 @@ int vps_deposit_fft_z(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const f
                       int quantity, int flags, void* zimg_dev, void* work_dev);
 int64_t vps_fft_y_chunk_elems(int N, int nx, int G, int nchunks, int chunk);   /* -1: G, nchunks do not divide */
 int vps_fft_y_packed(vps_ctx* ctx, int N);   /* 1: vps_fft_y packs rows now (binning-only scope with a row cut for N) */
-int64_t vps_fft_y_chunk_block(vps_ctx* ctx, int N, int nx, int G, int nchunks, int chunk, int packed);   /* -1: bad */
+int64_t vps_fft_y_chunk_block(vps_ctx* ctx, int N, int nx, int G, int nchunks, int chunk, int packed);   /* pure size query (host tables only). -1: bad arguments, -2: G x nchunks does not divide N/2, -3: packed without a row cut (vps_last_error says which) */
 int vps_fft_y(vps_ctx* ctx, int N, int nx, const void* zimg_dev, int G, int nchunks, int chunk, void* out_dev);
 
 /* x pass over `nlines` lines of length N.  Line i is made of nseg segments of

@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cmath>
 #include <cstdlib>
+#include <string>
 
 #include "vps_internal.h"
 
@@ -46,9 +47,44 @@ vps_launch_timer::~vps_launch_timer() {
   if (idx >= 0) (void)hipEventRecord(ctx->launches[idx].stop, ctx->stream);
 }
 
+// ---- options ---------------------------------------------------------------------------------------------------------------
+static const char* const k_option_names[] = {
+    "no_fast_binning",    // 1: the general (shell-walk) binning path even for symmetric tables / uniform edges (tests)
+    "no_pair_binning",    // 1: the x pass does not pair line ky with N - ky (tests)
+    "nn_query_centric",   // 1: exact NN by the query-centric ring search even on uniform lattices (tests)
+    "nn_kappa",           // scatter radius factor of the particle-centric NN search (tuning; default 1.15)
+    "nn_stats",           // 1: count (and print) the lattice points the NN scatter pass leaves to the exact fallback
+    "sort_groups",        // level-2 workgroups the two-level bucket sort aims for (tuning; default 512)
+    "sort_staged",        // 0: level-1 records scattered directly instead of LDS-staged runs (tests)
+    "sort_atomic",        // 1: one returning global atomic per particle instead of the two-level sort (tests)
+    "nn_ablate",          // timing-only builds (-DVPS_TIMING_VARIANTS): ignored otherwise
+};
+static std::map<std::string, double>& option_map() {
+  static std::map<std::string, double> m;
+  return m;
+}
+double vps_option(const char* name, double dflt) {
+  auto& m = option_map();
+  auto it = m.find(name);
+  return it == m.end() ? dflt : it->second;
+}
+
 extern "C" {
 
-int vps_version(void) { return 2; }
+int vps_version(void) { return 3; }
+
+int vps_set_option(const char* name, double value) {
+  if (!name) return vps_fail(nullptr, VPS_ERR_ARG, "vps_set_option: null name");
+  for (const char* n : k_option_names)
+    if (!strcmp(n, name)) {
+      if (value != value) option_map().erase(name);   // NaN: back to the default
+      else option_map()[name] = value;
+      return VPS_OK;
+    }
+  return vps_fail(nullptr, VPS_ERR_ARG, "vps_set_option: unknown option '%s'", name);
+}
+
+double vps_get_option(const char* name, double dflt) { return name ? vps_option(name, dflt) : dflt; }
 
 int vps_create(vps_ctx** out, int device_id) {
   if (!out) return vps_fail(nullptr, VPS_ERR_ARG, "vps_create: null out pointer");
@@ -223,8 +259,8 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
     if (!(thr_host[i] <= thr_host[i + 1]))
       return vps_fail(ctx, VPS_ERR_ARG, "vps_set_binning: thresholds must be non-decreasing (i=%d)", i);
   // mirrored-kx fast path of the x pass: k2[N-i] == k2[i] and k2 non-decreasing on [0, N/2]
-  // (VPS_NO_FAST_BINNING=1 forces the general path, for tests)
-  bool fast = (N % 2 == 0) && !getenv("VPS_NO_FAST_BINNING");
+  // (option no_fast_binning forces the general path, for tests)
+  bool fast = (N % 2 == 0) && vps_option("no_fast_binning", 0) == 0;
   for (int i = 1; fast && i < N / 2; ++i) fast = (k2_axis_host[N - i] == k2_axis_host[i]);
   for (int i = 0; fast && i < N / 2; ++i) fast = (k2_axis_host[i] <= k2_axis_host[i + 1]);
   // ... and uniform edges, so that the float guess (sqrt(s)-edge0)*inv_spacing is within one

@@ -782,29 +782,19 @@ struct DepLayout {
   SortGeom geom;
 };
 
-// groups per launch the two-level sort aims for (level-2 workgroups); VPS_SORT_GROUPS overrides (tuning)
+// groups per launch the two-level sort aims for (level-2 workgroups); option sort_groups overrides (tuning)
 int sort_target_groups() {
-  static int v = 0;
-  if (!v) {
-    const char* e = getenv("VPS_SORT_GROUPS");
-    v = e ? atoi(e) : 512;
-    if (v < 1) v = 1;
-    if (v > 4096) v = 4096;
-  }
+  int v = (int)vps_option("sort_groups", 512);
+  if (v < 1) v = 1;
+  if (v > 4096) v = 4096;
   return v;
 }
 
-bool sort_staged() {
-  const char* e = getenv("VPS_SORT_STAGED");
-  return !e || e[0] != '0';
-}
+bool sort_staged() { return vps_option("sort_staged", 1) != 0; }
 
-// VPS_SORT_ATOMIC=1 forces the one-atomic-per-particle ranking (kept for bucket counts / key ranges the
+// option sort_atomic forces the one-atomic-per-particle ranking (kept for bucket counts / key ranges the
 // two-level sort does not cover, and as a cross-check in the tests)
-bool sort_force_atomic() {
-  const char* e = getenv("VPS_SORT_ATOMIC");
-  return e && e[0] == '1';
-}
+bool sort_force_atomic() { return vps_option("sort_atomic", 0) != 0; }
 
 DepLayout dep_layout(int64_t np, int C, const Bricks& b) {
   DepLayout l;

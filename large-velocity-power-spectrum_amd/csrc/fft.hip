@@ -2019,11 +2019,31 @@ static int ypack_get(vps_ctx* ctx, int N, int G, int nchunks, int chunk, bool pa
 
 int vps_fft_y_packed(vps_ctx* ctx, int N) { return ctx && ypack_wanted(ctx, N) ? 1 : 0; }
 
+// A pure size query: the rows of a block follow from the host copy of the row cut; no device table is built or touched
+// (ypack_get, which the y / x passes call, keeps its one-entry cache for the launch that follows).
+// Returns -1: bad arguments, -2: G x nchunks does not divide N/2 (or G does not divide N), -3: packed without a row cut.
 int64_t vps_fft_y_chunk_block(vps_ctx* ctx, int N, int nx, int G, int nchunks, int chunk, int packed) {
-  if (!ctx || nx < 1) return -1;
-  vps_device_guard guard(ctx);
+  if (!ctx || nx < 1 || N < 2) return -1;
+  if (G < 1 || nchunks < 1 || chunk < 0 || chunk >= nchunks) return -1;
+  if (N % G || (N / 2) % (G * nchunks)) {
+    vps_fail(ctx, VPS_ERR_ARG, "chunked exchange: G=%d ranks x %d chunks must divide N/2=%d (and G divide N)", G, nchunks, N / 2);
+    return -2;
+  }
+  if (packed && (int)ctx->h_kcut.size() != N / 2 + 1) {
+    vps_fail(ctx, VPS_ERR_ARG, "chunked exchange: packed rows need the row cut of vps_set_binning(N=%d)", N);
+    return -3;
+  }
+  const int nkc = N / 2 / G / nchunks;
   long long rows = 0;
-  if (ypack_get(ctx, N, G, nchunks, chunk, packed != 0, nullptr, &rows)) return -1;
+  for (int j = 0; j < nkc; ++j) {
+    int kc = -1;
+    if (packed) {
+      kc = 0;
+      for (int h = 0; h < G; ++h) kc = std::max(kc, ctx->h_kcut[chunk * G * nkc + j * G + h]);
+      if (2 * kc + 1 >= N) kc = -1;
+    }
+    rows += kc < 0 ? N : 2 * kc + 1;
+  }
   return rows * nx + (chunk == nchunks - 1 ? (long long)(N / G) * nx : 0);
 }
 
@@ -2218,7 +2238,7 @@ static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz
     p.inv_spacing = (float)ctx->inv_spacing;
     p.psum = psum_dev;
     p.nsample = nsample_dev;
-    p.pair = (ctx->bin_fast && line0 % N == 0 && nlines % N == 0 && !getenv("VPS_NO_PAIR_BINNING")) ? 1 : 0;
+    p.pair = (ctx->bin_fast && line0 % N == 0 && nlines % N == 0 && vps_option("no_pair_binning", 0) == 0) ? 1 : 0;
     if (mode == 0) {
       rc = route_x(ctx, N, 0, 1, p, ctx->bin_fast ? 1 : 0);
     } else {

@@ -913,7 +913,7 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
   // uniform lattice (both reference lattices): particle-centric scatter + exact fallback for the few open points
-  if (model.uniform && nq_slab < 0xffffffffLL && !getenv("VPS_NN_QUERY_CENTRIC")) {
+  if (model.uniform && nq_slab < 0xffffffffLL && vps_option("nn_query_centric", 0) == 0) {
     NnScatterParams sp{};
     sp.srec = srec;
     sp.start = start;
@@ -921,10 +921,13 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
     sp.qx = dqx; sp.qy = dqy; sp.qz = dqz;
     sp.x0 = x0; sp.nx = nx; sp.nqy = nqy; sp.nqz = nqz;
     for (int a = 0; a < 3; ++a) { sp.a0[a] = model.a0[a]; sp.h[a] = model.h[a]; sp.slack[a] = (float)(model.dev[a] + 2e-3); }
-    const char* kenv = getenv("VPS_NN_KAPPA");
-    sp.kappa = kenv ? (float)atof(kenv) : 1.15f;
+    sp.kappa = (float)vps_option("nn_kappa", 1.15);
     if (!(sp.kappa > 0.2f && sp.kappa < 8.f)) sp.kappa = 1.15f;
-    sp.ablate = getenv("VPS_NN_ABLATE") ? 1 : 0;
+#ifdef VPS_TIMING_VARIANTS
+    sp.ablate = vps_option("nn_ablate", 0) != 0 ? 1 : 0;   // timing-only build: garbage results
+#else
+    sp.ablate = 0;
+#endif
     sp.payload = payload;
     sp.out = out;
     sp.vol = vol;
@@ -952,12 +955,12 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
 #undef VPS_NNS
     }
     VPS_HIP_CHECK(ctx, hipGetLastError());
-    if (ctx->timing || getenv("VPS_NN_STATS")) {   // diagnostics: how many points the scatter pass left open
+    if (ctx->timing || vps_option("nn_stats", 0) != 0) {   // diagnostics: how many points the scatter pass left open
       unsigned open_pts = 0;
       VPS_HIP_CHECK(ctx, hipMemcpyAsync(&open_pts, sp.list_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
       VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
       ctx->nn_open_points = open_pts;
-      if (getenv("VPS_NN_STATS")) fprintf(stderr, "[vps] nn: %u of %lld lattice points left to the exact fallback\n", open_pts, nq_slab);
+      if (vps_option("nn_stats", 0) != 0) fprintf(stderr, "[vps] nn: %u of %lld lattice points left to the exact fallback\n", open_pts, nq_slab);
     }
     return VPS_OK;
   }

@@ -72,6 +72,8 @@ struct vps_ctx {
 };
 
 int vps_fail(vps_ctx* ctx, int code, const char* fmt, ...);
+// Tuning / test switches set by the host through vps_set_option (process-wide; the library never reads the environment).
+double vps_option(const char* name, double dflt);
 
 // Every entry point of the C ABI runs with the context's device current and restores the caller's
 // on return: the library allocates (tables, partial sums, lattice axes) and launches on streams

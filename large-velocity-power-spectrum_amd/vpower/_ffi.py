@@ -29,6 +29,8 @@ SYMBOLS = (
     ("vps_set_stream", C.c_int, (_vp, _vp)),
     ("vps_sync", C.c_int, (_vp,)),
     ("vps_version", C.c_int, ()),
+    ("vps_set_option", C.c_int, (C.c_char_p, C.c_double)),
+    ("vps_get_option", C.c_double, (C.c_char_p, C.c_double)),
     ("vps_device_info", C.c_int, (_vp, C.POINTER(_i64))),
     ("vps_malloc", C.c_int, (_vp, C.POINTER(_vp), C.c_size_t)),
     ("vps_free", C.c_int, (_vp, _vp)),
@@ -178,7 +180,52 @@ def lib():
         fn.restype = res
         fn.argtypes = list(args)
     _lib = handle
+    _apply_env_options()
     return _lib
+
+
+# Switches of the library (include/vps_hip.h: vps_set_option).  The library itself never reads the environment; the
+# variables VPS_OPT_<NAME> (e.g. VPS_OPT_NN_KAPPA=1.3) are mapped ONCE, here, and recorded in OPTIONS so that a run can
+# report them.
+OPTION_NAMES = ("no_fast_binning", "no_pair_binning", "nn_query_centric", "nn_kappa", "nn_stats", "sort_groups",
+                "sort_staged", "sort_atomic", "nn_ablate")
+OPTIONS = {}
+
+
+def set_option(name, value):
+    """value None restores the default."""
+    v = float("nan") if value is None else float(value)
+    if lib().vps_set_option(name.encode(), v) != 0:
+        raise VpsError("unknown library option %r" % name)
+    if value is None:
+        OPTIONS.pop(name, None)
+    else:
+        OPTIONS[name] = float(value)
+
+
+class option:
+    """with _ffi.option("nn_query_centric", 1): ...  -- sets a switch for the duration of the block."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = OPTIONS.get(self.name)
+        set_option(self.name, self.value)
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.prev)
+        return False
+
+
+def _apply_env_options():
+    for n in OPTION_NAMES:
+        v = os.environ.get("VPS_OPT_" + n.upper())
+        if v is not None:
+            try:
+                set_option(n, float(v))
+            except ValueError:
+                raise VpsError("VPS_OPT_%s=%r is not a number" % (n.upper(), v))
 
 
 def as_dp(arr):

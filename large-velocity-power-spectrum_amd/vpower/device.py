@@ -479,7 +479,9 @@ class HipKernels:
         """Elements of ONE destination's block of chunk `chunk` (include/vps_hip.h: vps_fft_y)."""
         n = int(self.lib.vps_fft_y_chunk_block(self.ctx, int(N), int(nx), int(G), int(nchunks), int(chunk), int(bool(packed))))
         if n < 0:
-            raise _ffi.VpsError("%d ranks x %d chunks do not divide N/2 = %d" % (G, nchunks, N // 2))
+            why = self.lib.vps_last_error(self.ctx).decode() if n < -1 else "bad arguments"
+            raise _ffi.VpsError("vps_fft_y_chunk_block(N=%d, nx=%d, G=%d, nchunks=%d, chunk=%d, packed=%d) failed (%d): %s"
+                                % (N, nx, G, nchunks, chunk, bool(packed), n, why))
         return n
 
     def fft_y_chunk(self, zimg, N, nx, G, nchunks, chunk, out=None):
@@ -733,21 +735,22 @@ class PowerPipeline:
 
     def start_zimages(self, zimgs):
         """First half of `accumulate_zimages`: per group of up to three components and per kz chunk, the y pass into
-        the send buffer and the all-to-all, all started asynchronously.  Returns what `finish_zimages` needs.  Between
-        the two calls the caller may enqueue other work (the next quantity's deposit + z pass): it overlaps the exchanges."""
+        the send buffer and the all-to-all, all started asynchronously.  Returns what `finish_zimages` needs (the
+        handles AND the row packing the send buffers were written with).  Between the two calls the caller may enqueue
+        other work (the next quantity's deposit + z pass): it overlaps the exchanges."""
         N, nx, G = self.N, self.nx, self.comm.world
         k = self.k
         C_ = self.nchunks
         group = 1 if os.environ.get("VPS_X_PER_COMPONENT") == "1" else 3
-        started = []
+        groups = []
         self.prepare()
         with self._bin_scope():
-            self._packed = k.y_packed(N) if hasattr(k, "y_packed") else False   # the blocks carry only the rows a shell can reach
+            packed = k.y_packed(N) if hasattr(k, "y_packed") else False   # the blocks carry only the rows a shell can reach
             for i in range(0, len(zimgs), group):
                 comps = zimgs[i:i + group]
-                started.append([[self.comm.all_to_all_start(k.fft_y_chunk(z, N, nx, G, C_, c)) for z in comps]
-                                for c in range(C_)])
-        return started
+                groups.append([[self.comm.all_to_all_start(k.fft_y_chunk(z, N, nx, G, C_, c)) for z in comps]
+                               for c in range(C_)])
+        return {"packed": packed, "groups": groups}
 
     def finish_zimages(self, started, psum=None, nsample=None, count=True):
         """Second half: as the chunks arrive, x pass + shell sums (up to three components share one binning launch per
@@ -759,15 +762,29 @@ class PowerPipeline:
         if psum is None:
             psum, nsample = self.new_accumulators()
         C_ = self.nchunks
-        nkz, nky = N // 2 // G, N // G
-        nkc = nkz // C_
-        for i, pending in enumerate(started):
+        for i, pending in enumerate(started["groups"]):
             cnt = count and i == 0
             for c in range(C_):
                 recvs = [self.comm.all_to_all_finish(h) for h in pending[c]]
                 pending[c] = None
-                k.fft_x_bin_chunk(recvs, N, nx, G, C_, c, r, self._packed, psum, nsample, count=cnt)
+                k.fft_x_bin_chunk(recvs, N, nx, G, C_, c, r, started["packed"], psum, nsample, count=cnt)
         return psum, nsample
+
+    def pipelined_quantities(self, producers, accumulators):
+        """Several quantities of ONE particle set, pipelined against each other's exchanges: producers[i]() enqueues
+        quantity i's deposit + z pass and returns its z images (one per component); its y passes and all-to-alls are
+        started at once, and only then are the PREVIOUS quantity's arrived chunks transformed and binned into
+        accumulators[i-1] = (psum, nsample) -- so the links carry quantity i while the device works on i-1 and i+1.
+        Two quantities' send / receive buffers are alive at a time.  (What `bench.py` runs for C4 on >= 4 ranks.)"""
+        prev = None
+        for i, produce in enumerate(producers):
+            started = self.start_zimages(produce())
+            if prev is not None:
+                self.finish_zimages(prev[1], *accumulators[prev[0]])
+            prev = (i, started)
+        if prev is not None:
+            self.finish_zimages(prev[1], *accumulators[prev[0]])
+        return accumulators
 
     def accumulate_zimages(self, zimgs, psum=None, nsample=None, count=True):
         """x-side of the transform for z images (HipKernels.fft_z / deposit_fft_z): per kz chunk, y pass into the

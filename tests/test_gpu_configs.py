@@ -101,6 +101,48 @@ def _sum_and_sumsq(f, planes=32):
     return s, q
 
 
+def _ngp_moments_float64(K, dpos, dvel, drho, N, L, quantities, rows=128):
+    """Oracle-side statistics of the NGP fields at sizes no host array can follow: per quantity the float64 sum and sum
+    of squares of every component field, from a restatement of interp.py:1010-1013 + 272-273 + 523-525 + 546 in torch
+    float64 on the GPU (torch is only the calculator: python-style floor division for the cell index, index_add_ of
+    [rho v, rho] per x-slab of `rows` planes, v = rho v / rho with empty cells 0, m = rho Lcell^3).  No library call."""
+    Lcell = L / N
+    vol = Lcell ** 3
+    lc = torch.tensor(Lcell, dtype=dpos.dtype, device=dpos.device)
+    cx = (torch.floor_divide(dpos[:, 0], lc) % N).to(torch.int64)
+    out = {q: [[0.0, 0.0] for _ in range(1 if q == "energy" else 3)] for q in quantities}
+    for x0 in range(0, N, rows):
+        sel = torch.nonzero((cx >= x0) & (cx < x0 + rows)).squeeze(1)
+        p = dpos[sel]
+        flat = ((cx[sel] - x0) * N + (torch.floor_divide(p[:, 1], lc) % N).to(torch.int64)) * N \
+            + (torch.floor_divide(p[:, 2], lc) % N).to(torch.int64)
+        del p
+        d = drho[sel].double()
+        n3 = rows * N * N
+        rho = torch.zeros(n3, dtype=torch.float64, device=dpos.device).index_add_(0, flat, d)
+        inv = torch.where(rho > 0, 1.0 / rho, torch.zeros_like(rho))
+        v = []
+        for c in range(3):
+            a = torch.zeros(n3, dtype=torch.float64, device=dpos.device).index_add_(0, flat, d * dvel[sel, c].double())
+            v.append(a * inv)
+            del a
+        m = rho * vol
+        del rho, inv, flat, d, sel
+        for q in quantities:
+            if q == "velocity":
+                fs = v
+            elif q == "momentum":
+                fs = [v[c] * m for c in range(3)]
+            else:
+                fs = [m * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2])]
+            for c, f in enumerate(fs):
+                out[q][c][0] += float(f.sum().item())
+                out[q][c][1] += float((f * f).sum().item())
+            del fs
+        del v, m
+    return out
+
+
 # ------------------------------------------- fused deposit + z/y passes, full-size lines ----
 @pytest.mark.parametrize("N,nx,x0,quantity", [(512, 16, 96, "velocity"), (512, 16, 496, "momentum"), (1024, 16, 512, "velocity"),
                                                (1024, 16, 0, "energy"), (2048, 16, 1200, "velocity"),
@@ -191,24 +233,18 @@ def test_config3_full_size_momentum_properties(K):
 def test_config4_full_size_properties(K):
     """C4 at full size on one GPU through bench.Workload (fused deposit + z pass at N = 2048,
     reuse of the bucket sort across the three quantities): per-bin shell counts exact for every
-    quantity, and Parseval over all modes for each quantity against statistics of the un-fused
-    brick-deposited grids."""
+    quantity, and Parseval over all modes for each quantity against float64 statistics of the NGP
+    fields computed oracle-side (_ngp_moments_float64: a torch restatement of the reference's rule,
+    no library deposit)."""
     import bench
     from vpower import device, synth as sy
     N, Np, off = sy.CONFIGS["C4"]
     L = 1.0
     dpos, dvel, drho = sy.particles_device(K, sy.BASE_SEED + off, Np, L)
-    # grid statistics first (one quantity's grids at a time: 103 GB for a vector field)
-    want = {}
-    for q in ("velocity", "momentum", "energy"):
-        g = K.deposit_field(dpos, dvel, drho, N, L, 0, N, device.QUANTITY[q])
-        tot = 0.0
-        for c in range(g.shape[0]):
-            s, sq = _sum_and_sumsq(g[c])
-            tot += 0.5 * (sq / N ** 3 - (s / N ** 3) ** 2)
-        want[q] = tot
-        del g
-        _free(K)
+    # Parseval targets from the oracle-side float64 restatement of the NGP fields (no HIP deposit involved)
+    mom = _ngp_moments_float64(K, dpos, dvel, drho, N, L, ("velocity", "momentum", "energy"))
+    want = {q: sum(0.5 * (sq / N ** 3 - (s_ / N ** 3) ** 2) for s_, sq in mom[q]) for q in mom}
+    _free(K)
     wl = bench.Workload(K, device.SlabComm(enabled=False), N, L, "ngp", ("velocity", "momentum", "energy"), "library",
                         dpos, dvel, drho)
     assert wl.fused
@@ -438,7 +474,7 @@ def test_context_device_need_not_be_current():
 
 
 # ------------------------------------------------- the two exact-NN search kernels ----
-def test_nn_scatter_and_query_centric_kernels_agree(K, monkeypatch):
+def test_nn_scatter_and_query_centric_kernels_agree(K):
     """Uniform lattices take the particle-centric scatter kernel, anything else the query-centric ring search;
     both are exact, so they agree with each other and with the oracle -- including clumps, voids larger than
     the scatter radius (finished by the fallback search), duplicated particles and a descending axis."""
@@ -453,9 +489,9 @@ def test_nn_scatter_and_query_centric_kernels_agree(K, monkeypatch):
     dpos = K.to_device(pos)
     ref = orc.exact_nn_lattice(pos, ax, ax, ax)
     _, i1 = K.nn_resample(dpos, payload, (ax, ax, ax), 0, N, want_index=True)
-    monkeypatch.setenv("VPS_NN_QUERY_CENTRIC", "1")
-    _, i2 = K.nn_resample(dpos, payload, (ax, ax, ax), 0, N, want_index=True)
-    monkeypatch.delenv("VPS_NN_QUERY_CENTRIC")
+    from vpower import _ffi
+    with _ffi.option("nn_query_centric", 1):
+        _, i2 = K.nn_resample(dpos, payload, (ax, ax, ax), 0, N, want_index=True)
     assert np.array_equal(i1.cpu().numpy().ravel(), ref) and np.array_equal(i2.cpu().numpy().ravel(), ref)
     # descending z axis, x-slab [8, 24): still the scatter kernel
     axr = ax[::-1].copy()
@@ -503,9 +539,12 @@ def test_chunked_y_pass_layout_emulated_ranks(K, N, G, C):
         for c in range(C):
             with (K.binning_only() if packed else contextlib.nullcontext()):
                 is_packed = K.y_packed(N)
-                sends = [K.fft_y_chunk(zimgs[g], N, nx, G, C, c) for g in range(G)]
+                blk = K.chunk_block(N, nx, G, C, c, is_packed)
+                # NaN-filled send buffers: a row the x pass reads without the y pass having written it would poison the sums
+                sends = [K.fft_y_chunk(zimgs[g], N, nx, G, C, c,
+                                       out=torch.full((G * blk,), complex(float("nan"), float("nan")), dtype=torch.complex64,
+                                                      device=K.device)) for g in range(G)]
             assert is_packed == (packed and N >= 128 and N % 2 == 0)
-            blk = K.chunk_block(N, nx, G, C, c, is_packed)
             assert blk <= nkc * N * nx + (nky * nx if c == C - 1 else 0)
             assert all(s_.numel() == G * blk for s_ in sends)
             total += G * blk
@@ -515,11 +554,114 @@ def test_chunked_y_pass_layout_emulated_ranks(K, N, G, C):
             del sends
         sent[packed] = total
         tab = pipe.finish(psum, ns)
+        assert np.isfinite(tab[:, 2]).all()
         assert np.array_equal(tab[:, 3], ref[:, 3])
         assert np.allclose(tab[:, 2], ref[:, 2], rtol=1e-6, atol=0)
     assert sent[True] <= sent[False]
     if N >= 256 and N % 16 == 0:
         assert sent[True] < 0.9 * sent[False]           # the default k range leaves a fifth of the rows unbinned
+
+
+def _slot_rows(pipe, N, G, C, c, packed):
+    """Host restatement of the packed block layout (include/vps_hip.h: vps_fft_y): per slot j of chunk c the pair
+    (kc, rows) -- kc = largest row cut of the slot's G planes (cut of a plane = last |ky| with fl(ky^2 + kz^2) < thr[nbins],
+    rounded up to 16 | 15), rows = 2 kc + 1 or all N -- and per PLANE its own cut."""
+    nkc = N // 2 // G // C
+    k2h = pipe.k2[: N // 2 + 1]
+
+    def cut(kz):
+        ok = np.nonzero(~((k2h + pipe.k2[kz]) >= pipe.thr[-1]))[0]
+        return -1 if len(ok) == 0 else min(int(ok[-1]) | 15, N // 2)
+    slots = []
+    for j in range(nkc):
+        kc = -1
+        if packed:
+            kc = max(0, max(cut(c * G * nkc + j * G + h) for h in range(G)))
+            if 2 * kc + 1 >= N:
+                kc = -1
+        slots.append((kc, N if kc < 0 else 2 * kc + 1))
+    return slots, cut
+
+
+def test_chunked_packed_exchange_at_4096_one_sender_slab(K):
+    """C5's multi-rank path at its real line length: the chunked + packed vps_fft_y -> vps_fft_x_bin_chunk at N = 4096,
+    G = 8 ranks, 4 chunks.  ONE sender's x-slab (512 rows of random data, its z image 34 GB) stands for all eight -- the
+    global field is that slab repeated along x --, so every receiver's buffer is the sender's block for it, eight times.
+    Checked: the size and row layout of every block against the documented packing; whole planes of the send buffers
+    (first / middle / last slot, several destinations, the Nyquist rows) against numpy's FFT of the z image; the buffers are
+    pre-filled with NaN, so any row that is read without having been written poisons the sums; shell counts exact; shell
+    sums of the packed exchange equal to those of the unpacked one."""
+    import contextlib
+    from vpower import device
+    N, G, C = 4096, 8, 4
+    nx, NH, nky = N // G, N // 2, N // G
+    nkc = NH // G // C
+    gen = torch.Generator(device=K.device)
+    gen.manual_seed(4096)
+    f = torch.randn((nx, N, N), dtype=torch.float32, device=K.device, generator=gen)
+    z = K.fft_z(f, N, nx)
+    del f
+    _free(K)
+    pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=device.SlabComm(enabled=False))
+    pipe.prepare()
+    counts = _shell_counts_exact(K, pipe)
+    B = z[: nx * NH * N].view(nx, NH, N)
+    BN = z[nx * NH * N:].view(nx, N)
+    nan = complex(float("nan"), float("nan"))
+    tabs, sent = {}, {}
+    for packed in (False, True):
+        psum, ns = K.zeros((pipe.nbins,), torch.float64), K.zeros((pipe.nbins,), torch.int64)
+        sent[packed] = 0
+        for c in range(C):
+            slots, cut = _slot_rows(pipe, N, G, C, c, packed)
+            rows_total = sum(r for _, r in slots)
+            with (K.binning_only() if packed else contextlib.nullcontext()):
+                assert K.y_packed(N) == packed
+                blk = K.chunk_block(N, nx, G, C, c, packed)
+                assert blk == rows_total * nx + (nky * nx if c == C - 1 else 0)
+                out = torch.full((G * blk,), nan, dtype=torch.complex64, device=K.device)
+                K.fft_y_chunk(z, N, nx, G, C, c, out=out)
+            sent[packed] += G * blk
+            # whole planes of the send buffer against numpy
+            for h, j in ((0, 0), (3, nkc // 2), (7, nkc - 1), (5, 1)):
+                kz = c * G * nkc + j * G + h
+                ref = np.fft.fft(B[:, kz, :].cpu().numpy().astype(np.complex128), axis=1).T      # [ky][x]
+                scale = np.sqrt(np.mean(np.abs(ref) ** 2))
+                kc, rows = slots[j]
+                r0 = sum(r for _, r in slots[:j])
+                got = out[h * blk + r0 * nx: h * blk + (r0 + rows) * nx].view(rows, nx).cpu().numpy()
+                own = cut(kz) if packed else N          # rows this plane itself can still bin (<= the slot's kc)
+                for pos_ in range(rows):
+                    ky = pos_ if (kc < 0 or pos_ <= kc) else N - (2 * kc + 1 - pos_)
+                    aky = min(ky, N - ky)
+                    if aky <= own:
+                        assert np.max(np.abs(got[pos_] - ref[ky])) / scale < 1e-5, (packed, c, h, j, ky)
+                    else:      # between the plane's own cut and the slot's: untouched (NaN) or written, never garbage
+                        assert np.isnan(got[pos_]).all() or np.max(np.abs(got[pos_] - ref[ky])) / scale < 1e-5
+            if c == C - 1:
+                refn = np.fft.fft(BN.cpu().numpy().astype(np.complex128), axis=1).T              # [ky][x]
+                scale = np.sqrt(np.mean(np.abs(refn) ** 2))
+                own = cut(NH) if packed else N
+                for h in (0, 2, 7):
+                    got = out[h * blk + rows_total * nx: (h + 1) * blk].view(nky, nx).cpu().numpy()
+                    for i in range(nky):
+                        ky = h * nky + i
+                        if min(ky, N - ky) <= own:
+                            assert np.max(np.abs(got[i] - refn[ky])) / scale < 1e-5, (packed, "nyq", ky)
+                        else:
+                            assert np.isnan(got[i]).all() or np.max(np.abs(got[i] - refn[ky])) / scale < 1e-5
+            for h in range(G):
+                recv = out[h * blk:(h + 1) * blk].repeat(G)          # all eight senders hold the same slab
+                K.fft_x_bin_chunk([recv], N, nx, G, C, c, h, packed, psum, ns)
+                del recv
+            del out
+        tabs[packed] = pipe.finish(psum, ns)
+        assert np.isfinite(tabs[packed][:, 2]).all()                  # no NaN row reached a shell sum
+        assert np.array_equal(tabs[packed][:, 3], counts)
+    assert np.allclose(tabs[True][:, 2], tabs[False][:, 2], rtol=1e-6, atol=0)
+    assert sent[True] < 0.85 * sent[False]
+    del z, B, BN
+    _free(K)
 
 
 def test_fused_z_images_equal_the_fused_zy_path(K):
@@ -580,11 +722,9 @@ def test_higher_order_assignment_and_deconvolution(K, assignment):
     sp2 = box.spctrm("momentum")
     assert np.allclose(sp2.Psum, sp0.Psum, rtol=1e-6)
     # the general (non mirrored) binning path applies the same factors
-    os.environ["VPS_NO_FAST_BINNING"] = "1"
-    try:
+    from vpower import _ffi
+    with _ffi.option("no_fast_binning", 1):
         sp3 = box.spctrm("momentum", deconvolve=True)
-    finally:
-        del os.environ["VPS_NO_FAST_BINNING"]
     assert np.array_equal(sp3.Nsample, r1[:, 3]) and np.allclose(sp3.Psum, r1[:, 2], rtol=PSUM_RTOL, atol=0)
 
 

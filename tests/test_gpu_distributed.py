@@ -151,3 +151,55 @@ def test_two_ranks_two_gpus_rccl(tmp_path):
         tab = np.load(tmp_path / f"tab_nccl_{r}.npy")
         assert np.array_equal(tab[:, 3], ref[:, 3])
         assert np.allclose(tab[:, 2], ref[:, 2], rtol=2e-5, atol=0)
+
+
+def _bench_pipelined_worker(rank, world, port, N, Np, chunks, per_component, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "large-velocity-power-spectrum_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["VPS_PIPELINE_QUANTITIES"] = "1"
+    os.environ["VPS_A2A_CHUNKS"] = str(chunks)
+    if per_component:
+        os.environ["VPS_X_PER_COMPONENT"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from vpower import device, synth
+        K = device.default_kernels(0)
+        pos, vel, mass, dens = synth.particles(41, Np, 1.0)
+        wl = bench.Workload(K, device.SlabComm(), N, 1.0, "ngp", ("velocity", "momentum", "energy"), "library",
+                            K.to_device(pos), K.to_device(vel), K.to_device(dens))
+        assert wl.pipelined and wl.pipe.chunked and wl.pipe.nchunks == chunks and wl.pipe.comm.world == world
+        tabs = wl.step()
+        tabs2 = wl.step()            # a second step reuses every buffer (z images, accumulators, sort workspace)
+        for q in tabs:
+            assert np.array_equal(tabs[q][:, 3], tabs2[q][:, 3]) and np.allclose(tabs[q][:, 2], tabs2[q][:, 2], rtol=1e-6)
+        np.save(os.path.join(out_dir, f"tabs_{rank}.npy"), np.stack([tabs[q] for q in ("velocity", "momentum", "energy")]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N,chunks,per_component", [(4, 128, 2, False), (4, 256, 4, False), (2, 128, 4, True)])
+def test_bench_quantity_pipelined_step_on_shared_gpu(tmp_path, world, N, chunks, per_component):
+    """The branch `bench.py --gpus 8` takes for C4 (bench.Workload.step with VPS_PIPELINE_QUANTITIES: fused deposit + z pass
+    of quantity q+1 and its packed-row y passes / exchanges issued before quantity q's x passes, the bucket sort reused, per-
+    quantity accumulators), with the real HIP kernels on 2 / 4 gloo ranks sharing the one GPU: every rank's three tables
+    against the oracle."""
+    import torch.multiprocessing as mp
+    from vpower import synth
+    Np = 400000
+    mp.spawn(_bench_pipelined_worker, args=(world, _free_port(), N, Np, chunks, per_component, str(tmp_path)), nprocs=world, join=True)
+    pos, vel, mass, dens = synth.particles(41, Np, 1.0)
+    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
+    v, m = orc.vm_from_vec_grid(orc.deposit_to_grid_fast(vec, pos, N, 1.0), 1.0 / N, zero_empty=True)
+    refs = [orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, 1.0 / N, q) for q in ("velocity", "momentum", "energy")]
+    for r in range(world):
+        tabs = np.load(tmp_path / f"tabs_{r}.npy")
+        for tab, ref in zip(tabs, refs):
+            assert np.array_equal(tab[:, 3], ref[:, 3])
+            assert np.allclose(tab[:, 2], ref[:, 2], rtol=2e-5, atol=0)
+            assert np.allclose(tab[:, 1], ref[:, 1], rtol=2e-5, atol=0)

@@ -75,13 +75,20 @@ def test_deposit_matches_oracle(K, C):
     assert np.allclose(np.concatenate(parts, axis=1), grid, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("env", [{"VPS_SORT_ATOMIC": "1"}, {"VPS_SORT_STAGED": "0"}, {"VPS_SORT_GROUPS": "7"}, {}])
+@pytest.mark.parametrize("opts", [{"sort_atomic": 1}, {"sort_staged": 0}, {"sort_groups": 7}, {}])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_deposit_sort_variants_are_exact_on_integers(K, monkeypatch, env, dtype):
+def test_deposit_sort_variants_are_exact_on_integers(K, opts, dtype):
     """Every bucket-sort flavour (two-level staged / two-level direct / one atomic per particle) feeds the same
     records to the accumulation: small-integer payloads make the float32 sums exact, so results must be EQUAL."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    import contextlib
+    from vpower import _ffi
+    with contextlib.ExitStack() as stack:
+        for k, v in opts.items():
+            stack.enter_context(_ffi.option(k, v))
+        _deposit_sort_variant_body(K, dtype)
+
+
+def _deposit_sort_variant_body(K, dtype):
     rng = np.random.default_rng(31)
     N, L, Np = 96, 2.0, 300000                       # N not a power of two: bricks with a ragged edge
     pos = (rng.random((Np, 3)) * L).astype(dtype)
@@ -271,23 +278,23 @@ def test_fused_binning_matches_oracle(K, N, L, flavour):
 
 
 @pytest.mark.parametrize("N,L", [(32, 1.0), (64, 2.5), (256, 1.0)])
-def test_general_binning_path_matches_fast_path(K, N, L, monkeypatch):
+def test_general_binning_path_matches_fast_path(K, N, L):
     """The branch-free mirrored-kx path and the general shell walk give the same counts
     (bit for bit) and sums; custom narrow bins exercise several shells per kx step."""
-    from vpower import device
+    from vpower import device, _ffi
     rng = np.random.default_rng(N + 1)
     fields = [K.to_device(rng.standard_normal((N, N, N)).astype(np.float32)) for _ in range(2)]
     out = {}
     for kres in (None, 0.37 * 2 * np.pi / L):
         for general in (False, True, "nopair"):
-            monkeypatch.delenv("VPS_NO_FAST_BINNING", raising=False)
-            monkeypatch.delenv("VPS_NO_PAIR_BINNING", raising=False)
-            if general is True:
-                monkeypatch.setenv("VPS_NO_FAST_BINNING", "1")
-            elif general == "nopair":
-                monkeypatch.setenv("VPS_NO_PAIR_BINNING", "1")
-            pipe = device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False), kres=kres)
-            out[general] = pipe.finish(*pipe.accumulate(fields))
+            _ffi.set_option("no_fast_binning", 1 if general is True else None)
+            _ffi.set_option("no_pair_binning", 1 if general == "nopair" else None)
+            try:
+                pipe = device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False), kres=kres)
+                out[general] = pipe.finish(*pipe.accumulate(fields))
+            finally:
+                _ffi.set_option("no_fast_binning", None)
+                _ffi.set_option("no_pair_binning", None)
         for other in (True, "nopair"):
             assert np.array_equal(out[False][:, 3], out[other][:, 3])
             assert np.allclose(out[False][:, 2], out[other][:, 2], rtol=1e-6, atol=0)
@@ -297,8 +304,6 @@ def test_general_binning_path_matches_fast_path(K, N, L, monkeypatch):
         ref[:, 1] /= np.where(ref[:, 0] > 0, 4 * np.pi * ref[:, 0] ** 2, 1)
         assert np.array_equal(out[False][:, 3], ref[:, 3])
         assert np.allclose(out[False][:, 2], ref[:, 2], rtol=PSUM_RTOL, atol=0)
-    monkeypatch.delenv("VPS_NO_FAST_BINNING", raising=False)
-    monkeypatch.delenv("VPS_NO_PAIR_BINNING", raising=False)
 
 
 @pytest.mark.parametrize("N", [16, 32, 64, 128])
@@ -726,3 +731,18 @@ def test_config2_properties(K):
     tab1 = pipe.finish(*pipe.accumulate([fields[0]]))
     assert np.array_equal(tab1[:, 3], tab2[:, 3])
     assert np.allclose(tab2[:, 2], 4 * tab1[:, 2], rtol=1e-6)
+    del grid, fields
+    K._work.clear()
+    torch.cuda.empty_cache()
+    # the step function bench.py times for C2 (fused deposit + z pass, y passes in a binning-only scope, component-summed
+    # binning x pass) at FULL size against the oracle at full size (float64 numpy: ~1 min on one core)
+    import bench
+    wl = bench.Workload(K, device.SlabComm(enabled=False), N, L, "ngp", ("velocity",), "library", dpos, K.to_device(vel),
+                        K.to_device(dens))
+    assert wl.fused and not wl.pipe.chunked
+    t_step = wl.step()["velocity"]
+    ora, _ = bench.oracle_tables("ngp", ("velocity",), "library", N, L, pos, vel, dens)
+    ref2 = np.asarray(ora["velocity"], dtype=np.float64)
+    assert np.array_equal(t_step[:, 3], ref2[:, 3]) and np.array_equal(t_step[:, 3], tab[:, 3])
+    assert np.allclose(t_step[:, 2], ref2[:, 2], rtol=PSUM_RTOL, atol=0)
+    assert np.allclose(t_step[:, 1], ref2[:, 1], rtol=PSUM_RTOL, atol=0)

@@ -24,7 +24,11 @@ def test_abi_exports_every_declared_symbol():
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vps_version() == 2
+    assert lib.vps_version() == 3
+    # option switches: explicit, process-wide, unknown names refused (the library never reads the environment)
+    assert lib.vps_set_option(b"nn_kappa", 1.3) == 0 and lib.vps_get_option(b"nn_kappa", 0.0) == 1.3
+    assert lib.vps_set_option(b"nn_kappa", float("nan")) == 0 and lib.vps_get_option(b"nn_kappa", 1.15) == 1.15
+    assert lib.vps_set_option(b"no_such_switch", 1.0) != 0
     assert lib.vps_fft_supported(512) == 1 and lib.vps_fft_supported(500) == 1 and lib.vps_fft_supported(768) == 1 and lib.vps_fft_supported(2000) == 1 and lib.vps_fft_supported(600) == 0
     assert lib.vps_fft_workspace_bytes(512, 512) == (512 * 256 * 512 + 512 * 512) * 8
     assert lib.vps_nn_workspace_bytes(10 ** 6, 0, 64 ** 3) > 10 ** 6 * 16 + 4 * 64 ** 3
@@ -43,6 +47,14 @@ def test_product_path_fails_loudly_without_gpu():
     rc = lib.vps_create(ctypes.byref(h), 0)
     assert rc < 0 and h.value is None
     assert b"HIP" in lib.vps_last_error(None) or b"device" in lib.vps_last_error(None)
+
+
+def test_library_does_not_read_the_environment():
+    """A stray VPS_* variable in a user's job must not change a code path: no getenv in the shipped sources."""
+    csrc = os.path.join(ROOT, "large-velocity-power-spectrum_amd", "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, fn)).read(), fn
 
 
 def test_package_never_imports_oracle():
