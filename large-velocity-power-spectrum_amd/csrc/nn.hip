@@ -471,6 +471,10 @@ struct NnScatterParams {
   int* nn_idx;
   unsigned* list;        // unresolved lattice points (offsets inside the slab), capacity = all points
   unsigned* list_count;
+  const float* tile_r;   // column kernel: search radius per tile (nn_tile_radius_kernel), or NULL: computed in the kernel
+#ifdef VPS_NN_STAMPS
+  unsigned long long* stamps;   // timing-only builds: cycles per phase, summed over waves
+#endif
 };
 
 // exclusive scan of a[0..1023] in LDS by 256 threads (4 entries each); returns the total
@@ -782,6 +786,520 @@ __global__ void __launch_bounds__(NT_THREADS) nn_scatter_kernel(const F* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Column-register search (the default where the lattice is about as fine as the particles are dense: a few lattice
+// points per particle, both BASELINE NN configs).  The scatter kernel above spends two thirds of its time around LDS
+// atomics issued from partly filled waves.  Here nothing is shared: a LANE owns a column of NC_TZ = 32 lattice points
+// (fixed ix, iy; all z of the tile) and keeps their running minima -- smallest and second-smallest float32 squared
+// distance and the winner's index -- in 96 registers; a WAVE owns an 8 x 8 patch of columns and walks, one particle at
+// a time, the list of particles whose R-disc meets its patch.  A particle's coordinates are wave-uniform (v_readlane
+// of a register that holds 64 list entries at once), every lane evaluates it against its own column, and only for
+// the 8 z-points of the particle's z-window [z0, z0 + 8), which is where its R-ball can reach (R <= (3.5 - slack) h_z
+// makes 8 points enough).  The window start decides which registers are touched, so the wave's list is counting-sorted
+// by z0 first and each of the 25 classes runs its own straight-line code with static register indices: per (particle,
+// z) one subtract, one fma, a median-of-three (new runner-up), a compare and two selects -- no LDS traffic, no atomics,
+// no divergence, results independent of any order.  About 90 pair evaluations per lattice point instead of the scatter
+// kernel's 12, at a tenth of the cost each.
+// Exactness is argued as for the scatter kernel: every particle within R of a point has been evaluated for it (the
+// staged region covers the tile + R, a wave's list every disc that meets its patch, a window every z within R); the
+// point is settled when the winner's screen (sqrt(b1) + 2 err)^2 lies inside R^2 and the runner-up outside that
+// screen; all other points (voids, near ties, duplicates) go to the list of nn_fallback_kernel.
+// The epilogue forms v = rho v / rho, m = rho Lcell^3 (or gathers the payload) and writes each lane's 32 consecutive
+// z as whole 128-byte lines.
+// ------------------------------------------------------------------------------------------------
+constexpr int NC_TX = 16, NC_TY = 16, NC_TZ = 32;
+constexpr int NC_THREADS = 256;
+constexpr int NC_WIN = 8;                       // z-points a particle is evaluated for
+constexpr int NC_NCLS = NC_TZ - NC_WIN + 1;     // window starts 0 .. 24
+constexpr int NC_SEG = 1280;                    // region particles staged in LDS at a time
+constexpr int NC_MAXCOL = 1024;
+
+// search radius of a tile from the particles in the cells c0..c1 that hold its lattice points
+__device__ __forceinline__ double nc_radius(const NnGrid& g, const int (&c0)[3], const int (&c1)[3], unsigned cnt, float kappa,
+                                            float slack_z, double hz) {
+  const double rcap = (0.5 * (NC_WIN - 1) - (double)slack_z) * fabs(hz) * 0.999;
+  const double vol = ((c1[0] - c0[0] + 1) * g.w[0]) * ((c1[1] - c0[1] + 1) * g.w[1]) * ((c1[2] - c0[2] + 1) * g.w[2]);
+  const double R = cnt ? (double)kappa * cbrt(vol / (double)cnt) : rcap;
+  return fmin(R, rcap);
+}
+
+// one thread per tile of the column kernel: its search radius (what the kernel's own prologue would compute, moved out of
+// its critical path -- the tile's cells, their particle count, kappa * n^(-1/3), the window cap)
+__global__ void __launch_bounds__(256) nn_tile_radius_kernel(const NnScatterParams p, long long ntiles, float* __restrict__ tile_r) {
+  const long long tile = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tile >= ntiles) return;
+  constexpr int TD[3] = {NC_TX, NC_TY, NC_TZ};
+  const int ntz = (p.nqz + NC_TZ - 1) / NC_TZ, nty = (p.nqy + NC_TY - 1) / NC_TY;
+  const int t0[3] = {(int)(tile / ((long long)ntz * nty)) * NC_TX, (int)((tile / ntz) % nty) * NC_TY, (int)(tile % ntz) * NC_TZ};
+  const int nq[3] = {p.nx, p.nqy, p.nqz};
+  const double* ax[3] = {p.qx + p.x0, p.qy, p.qz};
+  const NnGrid& g = p.g;
+  int c0[3], c1[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int nt = min(TD[a], nq[a] - t0[a]);
+    const double qa = ax[a][t0[a]], qb = ax[a][t0[a] + nt - 1];
+    c0[a] = cell_coord(fmin(qa, qb), g.lo[a], g.inv_w[a], g.M);
+    c1[a] = cell_coord(fmax(qa, qb), g.lo[a], g.inv_w[a], g.M);
+  }
+  unsigned cnt = 0;
+  for (int cx = c0[0]; cx <= c1[0]; ++cx)
+    for (int cy = c0[1]; cy <= c1[1]; ++cy) {
+      const long long row = ((long long)cx * g.M + cy) * g.M;
+      cnt += p.start[row + c1[2] + 1] - p.start[row + c0[2]];
+    }
+  tile_r[tile] = (float)nc_radius(g, c0, c1, cnt, p.kappa, p.slack[2], p.h[2]);
+}
+
+__device__ __forceinline__ float nc_readlane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// all particles of window class Z0 in this wave's list: entries [beg, end) of ord
+template <int Z0>
+__device__ __forceinline__ void nc_run_class(float (&b1)[NC_TZ], float (&b2)[NC_TZ], int (&bi)[NC_TZ],
+                                             const float4* __restrict__ P, const unsigned short* __restrict__ ord,
+                                             unsigned beg, unsigned end, const float* __restrict__ qfz, float qxl, float qyl,
+                                             int lane) {
+  if (beg >= end) return;   // (wave-uniform)
+  float qz[NC_WIN];
+#pragma unroll
+  for (int k = 0; k < NC_WIN; ++k) qz[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qfz[Z0 + k])));
+  float4 nxt = P[ord[beg + (unsigned)lane < end ? beg + (unsigned)lane : beg]];   // 64 list entries, one per lane
+  for (unsigned k0 = beg; k0 < end; k0 += 64) {
+    const float4 rec = nxt;
+    {   // the following 64 entries are requested now and land while these are worked through
+      const unsigned me = k0 + 64u + (unsigned)lane;
+      nxt = P[ord[me < end ? me : beg]];
+    }
+    const int cnt = (int)min(64u, end - k0);
+    for (int i = 0; i < cnt; ++i) {
+      const float px = nc_readlane(rec.x, i), py = nc_readlane(rec.y, i), pz = nc_readlane(rec.z, i);
+      const int idx = __builtin_amdgcn_readlane(__float_as_int(rec.w), i);
+      const float fx = qxl - px, fy = qyl - py;
+      const float t2 = fmaf(fy, fy, fx * fx);
+#pragma unroll
+      for (int k = 0; k < NC_WIN; ++k) {
+        const float fz = qz[k] - pz;
+        const float d2 = fmaf(fz, fz, t2);
+        b2[Z0 + k] = __builtin_amdgcn_fmed3f(b1[Z0 + k], b2[Z0 + k], d2);   // b1 <= b2: the middle one is the new runner-up
+        const bool lt = d2 < b1[Z0 + k];
+        bi[Z0 + k] = lt ? idx : bi[Z0 + k];
+        b1[Z0 + k] = lt ? d2 : b1[Z0 + k];
+      }
+    }
+  }
+}
+
+template <int Z0>
+__device__ __forceinline__ void nc_run_all(float (&b1)[NC_TZ], float (&b2)[NC_TZ], int (&bi)[NC_TZ],
+                                           const float4* __restrict__ P, const unsigned short* __restrict__ ord,
+                                           const unsigned* __restrict__ cend, const float* __restrict__ qfz, float qxl,
+                                           float qyl, int lane) {
+  const unsigned beg = Z0 ? cend[Z0 - 1] : 0u, end = cend[Z0];
+  nc_run_class<Z0>(b1, b2, bi, P, ord, __builtin_amdgcn_readfirstlane(beg), __builtin_amdgcn_readfirstlane(end), qfz, qxl,
+                   qyl, lane);
+  if constexpr (Z0 + 1 < NC_NCLS) nc_run_all<Z0 + 1>(b1, b2, bi, P, ord, cend, qfz, qxl, qyl, lane);
+}
+
+template <typename F, int C>
+__global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __restrict__ pos, const NnScatterParams p) {
+  // one LDS block [ P | order | colbase | colg0 ]; the epilogue re-uses its head as the winners' image
+  constexpr int NC_SMEM = NC_SEG * 16 + 4 * NC_SEG * 2 + (NC_MAXCOL + 4) * 4 + NC_MAXCOL * 4;
+  constexpr int NC_IMG = 64 * 33;                        // ints per wave: [column][z], one pad word per column
+  static_assert(4 * NC_IMG * 4 <= NC_SEG * 16 + 4 * NC_SEG * 2 + (NC_MAXCOL + 4) * 4, "winner image must fit the staging block");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NC_SMEM];
+  float4* P = reinterpret_cast<float4*>(smem);                                         // staged region particles: tile-relative position, index
+  unsigned short (*order)[NC_SEG] = reinterpret_cast<unsigned short (*)[NC_SEG]>(smem + NC_SEG * 16);   // per wave: its particles, sorted by z-window start
+  unsigned* colbase = reinterpret_cast<unsigned*>(smem + NC_SEG * 16 + 4 * NC_SEG * 2);   // [NC_MAXCOL + 4] exclusive prefix of the column run lengths
+  unsigned* colg0 = colbase + NC_MAXCOL + 4;                                            // [NC_MAXCOL] first record of each column's z run
+  __shared__ float qf[3][NC_TZ];                        // lattice coordinates relative to the tile centre
+  __shared__ unsigned cls[4][32];                       // per wave: class counts -> offsets -> ends
+  __shared__ unsigned wsum[4];
+  __shared__ unsigned s_count, s_n;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef VPS_NN_STAMPS
+  unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#define NC_STAMP(i)                                                                         \
+  do {                                                                                      \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                           \
+    if (lane == 0) atomicAdd(&p.stamps[i], now_ - st_prev);                                 \
+    st_prev = __builtin_amdgcn_s_memtime();                                                 \
+  } while (0)
+#else
+#define NC_STAMP(i) do {} while (0)
+#endif
+  constexpr int TD[3] = {NC_TX, NC_TY, NC_TZ};
+  const int ntz = (p.nqz + NC_TZ - 1) / NC_TZ, nty = (p.nqy + NC_TY - 1) / NC_TY;
+  const long long tile = blockIdx.x;
+  const int t0[3] = {(int)(tile / ((long long)ntz * nty)) * NC_TX, (int)((tile / ntz) % nty) * NC_TY, (int)(tile % ntz) * NC_TZ};
+  const int nq[3] = {p.nx, p.nqy, p.nqz};
+  const double* ax[3] = {p.qx + p.x0, p.qy, p.qz};
+  int nt[3];
+  double lo[3], hi[3], org[3];
+  const NnGrid& g = p.g;
+  const int M = g.M;
+  const unsigned* __restrict__ start = p.start;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    nt[a] = min(TD[a], nq[a] - t0[a]);
+    const double qa = ax[a][t0[a]], qb = ax[a][t0[a] + nt[a] - 1];
+    lo[a] = fmin(qa, qb);
+    hi[a] = fmax(qa, qb);
+    org[a] = 0.5 * (qa + qb);
+  }
+  if (tid < 3 * NC_TZ) {
+    const int a = tid / NC_TZ, i = tid % NC_TZ;
+    qf[a][i] = (float)(ax[a][t0[a] + min(i, nt[a] - 1)] - org[a]);
+  }
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+
+  // ---- local density -> search radius (as in nn_scatter_kernel), capped by what a window of NC_WIN z-points covers ----
+  const double hmax = fmax(fabs(p.h[0]), fmax(fabs(p.h[1]), fabs(p.h[2])));
+  double R;
+  if (p.tile_r) {
+    R = (double)p.tile_r[tile];     // nn_tile_radius_kernel did this once for all tiles (one dependent round trip less here)
+  } else {
+    int c0[3], c1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      c0[a] = cell_coord(lo[a], g.lo[a], g.inv_w[a], M);
+      c1[a] = cell_coord(hi[a], g.lo[a], g.inv_w[a], M);
+    }
+    const int ny0 = c1[1] - c0[1] + 1, ncol0 = (c1[0] - c0[0] + 1) * ny0;
+    unsigned cnt = 0;
+    for (int col = tid; col < ncol0; col += NC_THREADS) {
+      const long long row = ((long long)(c0[0] + col / ny0) * M + (c0[1] + col % ny0)) * M;
+      cnt += start[row + c1[2] + 1] - start[row + c0[2]];
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if (lane == 0 && cnt) atomicAdd(&s_count, cnt);
+    __syncthreads();
+    R = nc_radius(g, c0, c1, s_count, p.kappa, p.slack[2], p.h[2]);
+  }
+  int r0[3], r1[3], ncy, ncol;
+  for (;;) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      r0[a] = cell_coord(lo[a] - R, g.lo[a], g.inv_w[a], M);
+      r1[a] = cell_coord(hi[a] + R, g.lo[a], g.inv_w[a], M);
+    }
+    ncy = r1[1] - r0[1] + 1;
+    ncol = (r1[0] - r0[0] + 1) * ncy;
+    if (ncol <= NC_MAXCOL) break;
+    R *= 0.7;
+  }
+  const float Rf = (float)R;
+  float halff[3];
+  double half = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    half = fmax(half, 0.5 * (hi[a] - lo[a]));
+    halff[a] = (float)(0.5 * (hi[a] - lo[a]));
+  }
+  // float32 error bound of a distance between tile-relative coordinates (nn_run: 2.5e-7 per unit of coordinate size)
+  const float err = (float)((2.0 * half + R + hmax) * 2.5e-7);
+  const float c_init = Rf * Rf;
+  const float reach = Rf * 1.00001f + 4.f * err;    // a particle farther than this from a box cannot be within R of its points
+  for (int col = tid; col < NC_MAXCOL; col += NC_THREADS) {
+    unsigned n = 0;
+    if (col < ncol) {
+      const long long row = ((long long)(r0[0] + col / ncy) * M + (r0[1] + col % ncy)) * M;
+      const unsigned g0 = start[row + r0[2]];
+      colg0[col] = g0;
+      n = start[row + r1[2] + 1] - g0;
+    }
+    colbase[col] = n;
+  }
+  __syncthreads();
+  const unsigned total = block_scan_1024(colbase, wsum, tid);
+
+  // this lane's column and this wave's patch
+  const int px0 = (wv & 1) * 8, py0 = (wv >> 1) * 8;
+  const int ix = px0 + (lane >> 3), iy = py0 + (lane & 7);
+  const float qxl = qf[0][min(ix, NC_TX - 1)], qyl = qf[1][min(iy, NC_TY - 1)];
+  float pcx, phx, pcy, phy;   // centre and half extent of the patch (tile-relative)
+  {
+    const float xa = qf[0][px0], xb = qf[0][px0 + 7], ya = qf[1][py0], yb = qf[1][py0 + 7];
+    pcx = 0.5f * (xa + xb); phx = 0.5f * fabsf(xb - xa);
+    pcy = 0.5f * (ya + yb); phy = 0.5f * fabsf(yb - ya);
+  }
+  const bool patch_live = px0 < nt[0] && py0 < nt[1];     // (wave-uniform) the patch holds lattice points at all
+  const float inv_hz = (float)(1.0 / p.h[2]);
+  const float a0z = (float)(p.a0[2] + (double)t0[2] * p.h[2] - org[2]);   // model coordinate of the tile's z index 0
+  // ---- staging: the next particles of the region that can lie within R of the tile -> P (tile-relative, compacted) ----
+  // Every thread takes up to NC_CAND candidates j = cursor + k * 256 + tid; all their loads are in flight together.  Slots are
+  // handed out in the order of j (per-wave ballots + a prefix over the 6 x 4 wave counts), so that when P overflows the cut is
+  // clean: everything from the first candidate without a slot on is staged by the next segment.
+  constexpr int NC_CAND = 6;
+  __shared__ unsigned wcnt[NC_CAND][4];
+  __shared__ unsigned s_next;
+  auto stage = [&](unsigned& cursor) -> unsigned {
+    __syncthreads();   // the previous segment's P / order are consumed
+    if (tid == 0) s_next = 0xffffffffu;
+    float4 rec[NC_CAND];
+    bool in[NC_CAND];
+#pragma unroll
+    for (int k = 0; k < NC_CAND; ++k) {
+      const unsigned j = cursor + (unsigned)(k * NC_THREADS + tid);
+      in[k] = j < total;
+      if (in[k]) {
+        int a_ = 0, b_ = ncol;   // column of item j: largest col with colbase[col] <= j
+        while (b_ - a_ > 1) {
+          const int m = (a_ + b_) >> 1;
+          if (colbase[m] <= j) a_ = m; else b_ = m;
+        }
+        rec[k] = srec_load(p.srec, colg0[a_] + (j - colbase[a_]));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NC_CAND; ++k) {
+      if (in[k]) {
+        double pd[3];
+        if constexpr (sizeof(F) == 4) {
+          pd[0] = (double)rec[k].x; pd[1] = (double)rec[k].y; pd[2] = (double)rec[k].z;
+        } else {
+          const long long oi = __float_as_int(rec[k].w);
+          pd[0] = pos[oi * 3 + 0]; pd[1] = pos[oi * 3 + 1]; pd[2] = pos[oi * 3 + 2];
+        }
+        rec[k].x = (float)(pd[0] - org[0]);
+        rec[k].y = (float)(pd[1] - org[1]);
+        rec[k].z = (float)(pd[2] - org[2]);
+        in[k] = fabsf(rec[k].x) <= halff[0] + reach && fabsf(rec[k].y) <= halff[1] + reach && fabsf(rec[k].z) <= halff[2] + reach;
+      }
+      const unsigned long long bal = __ballot(in[k]);
+      if (lane == 0) wcnt[k][wv] = (unsigned)__popcll(bal);
+    }
+    __syncthreads();
+    unsigned run = 0, n_all = 0;
+#pragma unroll
+    for (int k = 0; k < NC_CAND; ++k) {
+      unsigned base = run;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const unsigned c_ = wcnt[k][w];
+        if (w < wv) base += c_;
+        run += c_;
+      }
+      const unsigned long long bal = __ballot(in[k]);
+      const unsigned slot = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+      if (in[k]) {
+        if (slot < (unsigned)NC_SEG) P[slot] = rec[k];
+        else atomicMin(&s_next, cursor + (unsigned)(k * NC_THREADS + tid));
+      }
+      n_all = run;
+    }
+    __syncthreads();
+    const unsigned nx_ = s_next;
+    cursor = nx_ != 0xffffffffu ? nx_ : min(cursor + (unsigned)(NC_CAND * NC_THREADS), total);
+    return min(n_all, (unsigned)NC_SEG);
+  };
+  unsigned cursor = 0;
+  NC_STAMP(0);
+  unsigned staged = total ? stage(cursor) : 0u;   // the first segment is staged before the 96 accumulator registers exist
+  NC_STAMP(1);
+  float b1[NC_TZ], b2[NC_TZ];
+  int bi[NC_TZ];
+#pragma unroll
+  for (int z = 0; z < NC_TZ; ++z) {
+    b1[z] = INFINITY;
+    b2[z] = INFINITY;
+    bi[z] = -1;
+  }
+  auto process = [&](const unsigned n) {
+    if (!patch_live || n == 0) return;   // (wave-uniform; stage()'s barriers are reached by every wave all the same)
+    // ---- this wave's list: particles whose R-disc meets the patch, counting-sorted by z-window start ----
+    if (lane < 32) cls[wv][lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    auto classify = [&](const float4 q) -> int {   // z-window start, or -1: not this wave's
+      const float dx = fmaxf(fabsf(q.x - pcx) - phx, 0.f), dy = fmaxf(fabsf(q.y - pcy) - phy, 0.f);
+      if (dx * dx + dy * dy > reach * reach) return -1;
+      const float u0 = (q.z - Rf - a0z) * inv_hz, u1 = (q.z + Rf - a0z) * inv_hz;
+      const int zl = (int)ceilf(fminf(u0, u1) - p.slack[2]), zh = (int)floorf(fmaxf(u0, u1) + p.slack[2]);
+      if (zh < 0 || zl > nt[2] - 1) return -1;
+      return min(max(zl, 0), NC_NCLS - 1);
+    };
+    for (unsigned s_ = lane; s_ < n; s_ += 64) {
+      const int c_ = classify(P[s_]);
+      if (c_ >= 0) atomicAdd(&cls[wv][c_], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const unsigned v = lane < 32 ? cls[wv][lane] : 0u;
+      unsigned incl = v;
+      for (int off = 1; off < 32; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 32) cls[wv][lane] = incl - v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (unsigned s_ = lane; s_ < n; s_ += 64) {
+      const int c_ = classify(P[s_]);
+      if (c_ >= 0) order[wv][atomicAdd(&cls[wv][c_], 1u)] = (unsigned short)s_;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // cls[wv][c] now holds the END of class c
+    NC_STAMP(2);
+    // (s_setprio 3 outside the class loops / 0 inside -- so that the latency-bound phases never queue behind another wave's
+    // VALU stream -- measured: 18.5 against 18.4 ms, no effect)
+    nc_run_all<0>(b1, b2, bi, P, order[wv], cls[wv], qf[2], qxl, qyl, lane);
+    NC_STAMP(3);
+  };
+  process(staged);
+  // regions of more than NC_SEG particles (clumps): further segments.  Rare -- and marked so, because staging next to the
+  // 96 live accumulators spills, which must not leak into the common path
+  while (__builtin_expect(cursor < total, 0)) {
+    staged = stage(cursor);
+    process(staged);
+  }
+
+  // ---- epilogue ----
+  // (1) settle test per point, the open ones appended to the fallback's list with ONE atomic per wave; (2) the winners go
+  // through an LDS image [column][z] so that 8 lanes share a column's 32 z: every store instruction then writes whole 128-byte
+  // lines, and a lane has four payload gathers per column in flight, two columns at a time.
+  __syncthreads();   // every wave is done with P / order: the block becomes the winners' image
+  NC_STAMP(5);
+  int* img = reinterpret_cast<int*>(smem) + wv * NC_IMG;
+  const long long nqs = (long long)p.nx * p.nqy * p.nqz;
+  {
+    const bool col_live = ix < nt[0] && iy < nt[1];
+    const long long q0 = ((long long)(t0[0] + ix) * p.nqy + (t0[1] + iy)) * p.nqz + t0[2];
+    unsigned open = 0;
+#pragma unroll
+    for (int z = 0; z < NC_TZ; ++z) {
+      // settled: the winner's whole screen lies inside the sphere of radius R (every particle that could beat or tie it was
+      // evaluated) and the runner-up lies outside that screen (the float32 winner is the exact one)
+      const float rb = sqrtf(b1[z]) * 1.000001f + 2.f * err;
+      const float screen = rb * rb * 1.000001f;
+      const bool ok = bi[z] >= 0 && screen <= c_init && b2[z] > screen;
+      if (!ok && z < nt[2] && col_live) open |= 1u << z;
+      img[lane * 33 + z] = max(bi[z], 0);
+    }
+    const unsigned mine = (unsigned)__popc(open);
+    unsigned incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    const unsigned wave_total = __builtin_amdgcn_readlane(incl, 63);
+    if (wave_total) {   // (wave-uniform)
+      unsigned base = 0;
+      if (lane == 63) base = atomicAdd(p.list_count, wave_total);
+      base = __builtin_amdgcn_readlane(base, 63) + incl - mine;
+      while (open) {
+        const int z = __builtin_ctz(open);
+        open &= open - 1;
+        p.list[base++] = (unsigned)(q0 + z);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  NC_STAMP(6);
+  const bool wide = nt[2] == NC_TZ && (p.nqz & 3) == 0 && (nqs & 3) == 0 &&
+                    (!p.out || (reinterpret_cast<size_t>(p.out) & 15) == 0) &&
+                    (!p.nn_idx || (reinterpret_cast<size_t>(p.nn_idx) & 15) == 0);
+  const int zc = lane & 7;
+  // round r handles the columns (lane >> 3) + 8 (2 r + u), u = 0, 1.  The gathers of round r + 1 are requested BEFORE the
+  // stores of round r are issued: a wave's memory operations retire in order, so gathers queued behind stores would wait
+  // for the stores' acknowledgement as well.
+  auto col_of = [&](int r, int u) { return (lane >> 3) + 8 * (2 * r + u); };
+  auto col_live = [&](int col) { return px0 + (col >> 3) < nt[0] && py0 + (col & 7) < nt[1]; };
+  auto col_q = [&](int col) {
+    return ((long long)(t0[0] + px0 + (col >> 3)) * p.nqy + (t0[1] + py0 + (col & 7))) * p.nqz + t0[2] + 4 * zc;
+  };
+  if (wide && C == 4 && p.out) {
+    if constexpr (C == 4) {
+      int w[2][2][4];
+      float4 v[2][2][4];
+      auto request = [&](int r, int slot) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int col = col_of(r, u);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[slot][u][k] = img[col * 33 + 4 * zc + k];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[slot][u][k] = *reinterpret_cast<const float4*>(p.payload + (long long)w[slot][u][k] * 4);
+        }
+      };
+      auto emit = [&](int r, int slot) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int col = col_of(r, u);
+          if (!col_live(col)) continue;
+          const long long q = col_q(col);
+          if (p.nn_idx) *reinterpret_cast<int4*>(p.nn_idx + q) = make_int4(w[slot][u][0], w[slot][u][1], w[slot][u][2], w[slot][u][3]);
+          float4 (&x)[4] = v[slot][u];
+          if (p.vol > 0.f) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float inv = x[k].w != 0.f ? 1.f / x[k].w : 0.f;
+              x[k] = make_float4(x[k].x * inv, x[k].y * inv, x[k].z * inv, x[k].w * p.vol);
+            }
+          }
+          float* o = p.out + q;
+          *reinterpret_cast<float4*>(o) = make_float4(x[0].x, x[1].x, x[2].x, x[3].x);
+          *reinterpret_cast<float4*>(o + nqs) = make_float4(x[0].y, x[1].y, x[2].y, x[3].y);
+          *reinterpret_cast<float4*>(o + 2 * nqs) = make_float4(x[0].z, x[1].z, x[2].z, x[3].z);
+          *reinterpret_cast<float4*>(o + 3 * nqs) = make_float4(x[0].w, x[1].w, x[2].w, x[3].w);
+        }
+      };
+      request(0, 0);
+      request(1, 1);
+      emit(0, 0);
+      request(2, 0);
+      emit(1, 1);
+      request(3, 1);
+      emit(2, 0);
+      emit(3, 1);
+    }
+  } else {
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int col = col_of(r, u);
+        if (!col_live(col)) continue;
+        const long long q = col_q(col);
+        int w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = img[col * 33 + 4 * zc + k];
+        if (wide) {
+          if (p.nn_idx) *reinterpret_cast<int4*>(p.nn_idx + q) = make_int4(w[0], w[1], w[2], w[3]);
+          if (p.out) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch)
+              *reinterpret_cast<float4*>(p.out + (long long)ch * nqs + q) =
+                  make_float4(p.payload[(long long)w[0] * C + ch], p.payload[(long long)w[1] * C + ch],
+                              p.payload[(long long)w[2] * C + ch], p.payload[(long long)w[3] * C + ch]);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (4 * zc + k < nt[2]) {
+              if (p.nn_idx) p.nn_idx[q + k] = w[k];
+              if (p.out) nn_emit<C>(p.payload, w[k], q + k, nqs, p.out, p.vol);
+            }
+        }
+      }
+    }
+  }
+  NC_STAMP(4);
+}
+
 // the lattice points the scatter pass could not settle: exact float64 ring search, one point per thread
 template <typename F, int C>
 __global__ void __launch_bounds__(256)
@@ -912,7 +1430,8 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
     hipLaunchKernelGGL(nn_fill_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np, g, start, fill, srec);
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
-  // uniform lattice (both reference lattices): particle-centric scatter + exact fallback for the few open points
+  // uniform lattice (both reference lattices): column-register search (lattice about as fine as the particles are dense) or
+  // particle-centric scatter, + exact fallback for the few open points
   if (model.uniform && nq_slab < 0xffffffffLL && vps_option("nn_query_centric", 0) == 0) {
     NnScatterParams sp{};
     sp.srec = srec;
@@ -934,14 +1453,38 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
     sp.nn_idx = nn_idx;
     sp.list = reinterpret_cast<unsigned*>(work + l.list);
     sp.list_count = reinterpret_cast<unsigned*>(work + l.list_count);
-    const long long tiles = (long long)((nx + NT_T - 1) / NT_T) * ((nqy + NT_T - 1) / NT_T) * ((nqz + NT_T - 1) / NT_T);
+#ifdef VPS_NN_STAMPS
+    static unsigned long long* d_stamps = nullptr;
+    if (!d_stamps) (void)hipMalloc(&d_stamps, 8 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(d_stamps, 0, 8 * sizeof(unsigned long long), ctx->stream);
+    sp.stamps = d_stamps;
+#endif
+    // Which search: a z-window of NC_WIN lattice points must hold the R-ball of a particle at the MEAN density (denser tiles
+    // shrink R, sparser ones are capped and leave more points to the fallback); option nn_column: 1 force, 0 never
+    const double slack_z = model.dev[2] + 2e-3;
+    const double rcap = (0.5 * (NC_WIN - 1) - slack_z) * std::fabs(model.h[2]) * 0.999;
+    const double spacing = std::cbrt((g.w[0] * l.M) * (g.w[1] * l.M) * (g.w[2] * l.M) / (double)np);
+    const double colopt = vps_option("nn_column", -1);
+    const bool column = colopt >= 0 ? colopt != 0 : (double)sp.kappa * spacing <= rcap;
+    const long long tiles = column ? (long long)((nx + NC_TX - 1) / NC_TX) * ((nqy + NC_TY - 1) / NC_TY) * ((nqz + NC_TZ - 1) / NC_TZ)
+                                   : (long long)((nx + NT_T - 1) / NT_T) * ((nqy + NT_T - 1) / NT_T) * ((nqz + NT_T - 1) / NT_T);
     if (tiles > 0x7fffffffLL) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "vps_nn_resample: too many queries for one launch");
     VPS_HIP_CHECK(ctx, hipMemsetAsync(sp.list_count, 0, sizeof(unsigned), ctx->stream));
+    sp.tile_r = nullptr;
+    if (column && tiles <= l.ncell) {   // (the cell counters are dead once the list is built: room for one float per tile)
+      float* tr = reinterpret_cast<float*>(count);
+      vps_launch_timer tm(ctx, VPS_K_NN_BUILD);
+      hipLaunchKernelGGL(nn_tile_radius_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, ctx->stream, sp, tiles, tr);
+      sp.tile_r = tr;
+    }
     {
       vps_launch_timer tm(ctx, VPS_K_NN_QUERY);
 #define VPS_NNS(CC)                                                                                            \
   do {                                                                                                         \
-    hipLaunchKernelGGL((nn_scatter_kernel<F, CC>), dim3((unsigned)tiles), dim3(NT_THREADS), 0, ctx->stream, pos, sp); \
+    if (column)                                                                                                \
+      hipLaunchKernelGGL((nn_column_kernel<F, CC>), dim3((unsigned)tiles), dim3(NC_THREADS), 0, ctx->stream, pos, sp); \
+    else                                                                                                       \
+      hipLaunchKernelGGL((nn_scatter_kernel<F, CC>), dim3((unsigned)tiles), dim3(NT_THREADS), 0, ctx->stream, pos, sp); \
     hipLaunchKernelGGL((nn_fallback_kernel<F, CC>), dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, ctx->stream, \
                        pos, srec, start, g, err, dqx, dqy, dqz, x0, nx, nqy, nqz, sp.list, sp.list_count, payload, \
                        out, nn_idx, vol);                                                                      \
@@ -955,6 +1498,17 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
 #undef VPS_NNS
     }
     VPS_HIP_CHECK(ctx, hipGetLastError());
+#ifdef VPS_NN_STAMPS
+    {
+      unsigned long long h_st[8];
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipMemcpy(h_st, d_stamps, sizeof(h_st), hipMemcpyDeviceToHost);
+      double tot = 0;
+      for (int i = 0; i < 7; ++i) tot += (double)h_st[i];
+      fprintf(stderr, "[vps] nn column stamps: setup %.1f%% stage %.1f%% lists %.1f%% classes %.1f%% barrier %.1f%% settle %.1f%% output %.1f%% (sum %.3g cycles)\n",
+              100 * h_st[0] / tot, 100 * h_st[1] / tot, 100 * h_st[2] / tot, 100 * h_st[3] / tot, 100 * h_st[5] / tot, 100 * h_st[6] / tot, 100 * h_st[4] / tot, tot);
+    }
+#endif
     if (ctx->timing || vps_option("nn_stats", 0) != 0) {   // diagnostics: how many points the scatter pass left open
       unsigned open_pts = 0;
       VPS_HIP_CHECK(ctx, hipMemcpyAsync(&open_pts, sp.list_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));

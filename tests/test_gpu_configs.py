@@ -493,6 +493,17 @@ def test_nn_scatter_and_query_centric_kernels_agree(K):
     with _ffi.option("nn_query_centric", 1):
         _, i2 = K.nn_resample(dpos, payload, (ax, ax, ax), 0, N, want_index=True)
     assert np.array_equal(i1.cpu().numpy().ravel(), ref) and np.array_equal(i2.cpu().numpy().ravel(), ref)
+    # the two uniform-lattice kernels, each forced: column-register search (lanes own z-columns, no atomics) and
+    # particle-centric scatter (LDS minima); with a payload, so that the fused epilogues are compared too
+    pay4 = K.to_device(rng.standard_normal((Np, 4)).astype(np.float32))
+    outs = []
+    for col in (1, 0):
+        with _ffi.option("nn_column", col):
+            o, ii = K.nn_resample(dpos, pay4, (ax, ax, ax), 0, N, want_index=True)
+        assert np.array_equal(ii.cpu().numpy().ravel(), ref), col
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0].reshape(4, -1), pay4[torch.as_tensor(ref, device=K.device).long()].T)
     # descending z axis, x-slab [8, 24): still the scatter kernel
     axr = ax[::-1].copy()
     _, i3 = K.nn_resample(dpos, payload, (ax, ax, axr), 8, 16, want_index=True)
