@@ -60,7 +60,7 @@ int vps_sync(vps_ctx* ctx);
 int vps_version(void);                            /* ABI version, currently 3       */
 /* Tuning / test switches, process-wide.  The library never reads the environment: a stray variable in a user's job cannot
  * change a code path; the host sets what it wants explicitly (vpower/_ffi.py maps VPS_OPT_<NAME> variables once, at load,
- * and lists them in _ffi.OPTIONS).  Names: no_fast_binning, no_pair_binning, nn_query_centric, nn_column, nn_kappa, nn_stats,
+ * and lists them in _ffi.OPTIONS).  Names: no_fast_binning, no_pair_binning, nn_query_centric, nn_column, nn_build_atomic, nn_kappa, nn_stats,
  * sort_groups, sort_staged, sort_atomic (all result-preserving), nn_ablate (timing-only builds; ignored by the product
  * build).  A NaN value restores the default.  Unknown names: VPS_ERR_ARG. */
 int vps_set_option(const char* name, double value);

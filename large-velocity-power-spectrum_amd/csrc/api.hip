@@ -54,6 +54,7 @@ static const char* const k_option_names[] = {
     "nn_query_centric",   // 1: exact NN by the query-centric ring search even on uniform lattices (tests)
     "nn_kappa",           // scatter radius factor of the particle-centric NN search (tuning; default 1.15)
     "nn_column",          // exact NN on uniform lattices: 1 force the column-register search, 0 never (default: by density)
+    "nn_build_atomic",    // 1: NN cell list by the counting sort with global atomics instead of the two-level LDS sort (tests)
     "nn_stats",           // 1: count (and print) the lattice points the NN scatter pass leaves to the exact fallback
     "sort_groups",        // level-2 workgroups the two-level bucket sort aims for (tuning; default 512)
     "sort_staged",        // 0: level-1 records scattered directly instead of LDS-staged runs (tests)

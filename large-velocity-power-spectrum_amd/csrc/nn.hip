@@ -52,14 +52,23 @@ __global__ void nn_init_header(NnHeader* h) {
 template <typename F>
 __global__ void __launch_bounds__(256) nn_bbox_kernel(const F* __restrict__ pos, long long np, NnHeader* h) {
   double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < np;
-       i += (long long)gridDim.x * blockDim.x) {
+  // four particles per thread and trip: twelve loads in flight (one per trip left the pass latency bound: 0.8 ms for 0.6 GB)
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < np; i0 += 4 * stride) {
+    F v[4][3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const double v = (double)pos[i * 3 + a];
-      lo[a] = fmin(lo[a], v);
-      hi[a] = fmax(hi[a], v);
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * stride;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) v[u][a] = i < np ? pos[i * 3 + a] : pos[i0 * 3 + a];
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = fmin(lo[a], (double)v[u][a]);
+        hi[a] = fmax(hi[a], (double)v[u][a]);
+      }
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -118,6 +127,211 @@ __global__ void __launch_bounds__(256)
   const long long c = ((long long)cx * g.M + cy) * g.M + cz;
   const unsigned slot = start[c] + atomicAdd(&fill[c], 1u);
   srec[slot] = make_float4((float)px, (float)py, (float)pz, __int_as_float((int)i));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cell list by a two-level LDS bucket sort (the scheme of deposit.hip, with a cell's linear index as the key): the
+// counting sort above pays one random global atomic per particle twice (count, fill: 2.2 + 4.5 ms at 5e7 particles) and
+// a random 16-byte store.  Here
+//   level 1: chunks of NB_CHUNK particles; per-chunk LDS histogram over groups of 2^gshift consecutive cells ->
+//            table[group][chunk] -> exclusive scan -> each chunk ranks its particles with LDS atomics, stages
+//            {record, key} in LDS in group order and streams every (chunk, group) run out contiguously;
+//   level 2: one workgroup per group: LDS histogram over the group's cells, LDS scan (-> start[]), second sweep places
+//            the records at their final slots (all inside the group's few hundred KB: the L2 merges them).
+// Records inside one cell come out in no particular order (as with the atomic fill).
+// ------------------------------------------------------------------------------------------------
+constexpr int NB_THREADS = 1024;
+constexpr int NB_ITEMS = 4;
+constexpr int NB_CHUNK = NB_THREADS * NB_ITEMS;
+constexpr int NB_MAXG_SHIFT = 15;         // cells per group <= 32768 (128 KB of LDS counters in level 2)
+constexpr int NB_MAXGROUPS = 2048;
+
+struct NbGeom {
+  int gshift, ngroups;
+  long long nchunks, ncell;
+};
+
+template <typename F>
+__device__ __forceinline__ unsigned nb_cell_of(const F* __restrict__ pos, long long i, const NnGrid& g) {
+  const int cx = cell_coord((double)pos[i * 3 + 0], g.lo[0], g.inv_w[0], g.M);
+  const int cy = cell_coord((double)pos[i * 3 + 1], g.lo[1], g.inv_w[1], g.M);
+  const int cz = cell_coord((double)pos[i * 3 + 2], g.lo[2], g.inv_w[2], g.M);
+  return (unsigned)((cx * g.M + cy) * g.M + cz);     // M <= 1024: fits 30 bits
+}
+
+template <typename F>
+__global__ void __launch_bounds__(NB_THREADS)
+    nb_hist_kernel(const F* __restrict__ pos, long long np, NnGrid g, NbGeom s, unsigned* __restrict__ keys,
+                   unsigned* __restrict__ table) {
+  extern __shared__ unsigned nb_lds[];
+  for (int i = threadIdx.x; i < s.ngroups; i += NB_THREADS) nb_lds[i] = 0;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * NB_CHUNK;
+#pragma unroll
+  for (int k = 0; k < NB_ITEMS; ++k) {
+    const long long i = base + (long long)k * NB_THREADS + threadIdx.x;
+    if (i < np) {
+      const unsigned key = nb_cell_of<F>(pos, i, g);
+      keys[i] = key;
+      atomicAdd(&nb_lds[key >> s.gshift], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < s.ngroups; i += NB_THREADS) table[(long long)i * s.nchunks + blockIdx.x] = nb_lds[i];
+}
+
+// exclusive scan of the LDS array a[0..n), n <= 4 * NB_THREADS, in place; returns the total (all threads call it)
+__device__ __forceinline__ unsigned nb_block_scan(unsigned* a, int n, unsigned* scratch) {
+  const int per = (n + NB_THREADS - 1) / NB_THREADS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned v[4], mine = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = tid * per + k;
+    v[k] = (k < per && idx < n) ? a[idx] : 0u;
+    mine += v[k];
+  }
+  unsigned inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned up = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += up;
+  }
+  if (lane == 63) scratch[wave] = inc;
+  __syncthreads();
+  unsigned before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < NB_THREADS / 64; ++w) {
+    const unsigned t = scratch[w];
+    if (w < wave) before += t;
+    total += t;
+  }
+  unsigned run = before + inc - mine;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = tid * per + k;
+    if (k < per && idx < n) {
+      a[idx] = run;
+      run += v[k];
+    }
+  }
+  __syncthreads();
+  return total;
+}
+
+// level-1 scatter, LDS-staged; consecutive chunks own adjacent runs of every group and are dealt to the SAME XCD
+// (blockIdx % 8, speed only) so that its L2 can merge the partly written lines at run boundaries
+template <typename F>
+__global__ void __launch_bounds__(NB_THREADS)
+    nb_scatter_kernel(const F* __restrict__ pos, long long np, const unsigned* __restrict__ keys, NbGeom s,
+                      const unsigned* __restrict__ table_start, float4* __restrict__ rec1, unsigned* __restrict__ key1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned nb_lds[];
+  float4* stage = reinterpret_cast<float4*>(nb_lds);                      // [NB_CHUNK]
+  unsigned* skey = nb_lds + NB_CHUNK * 4;                                  // [NB_CHUNK]
+  unsigned* gdest = skey + NB_CHUNK;                                       // [NB_CHUNK] global slot of staged record p
+  unsigned* gbase = gdest + NB_CHUNK;                                      // [ngroups] first global slot of this chunk's run
+  unsigned* lstart = gbase + s.ngroups;                                    // [ngroups] counts, then local exclusive starts
+  unsigned* scratch = lstart + s.ngroups;                                  // [NB_THREADS / 64]
+  const long long per_xcd = (s.nchunks + 7) / 8;
+  const long long chunk = (long long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (chunk >= s.nchunks) return;
+  for (int i = threadIdx.x; i < s.ngroups; i += NB_THREADS) {
+    gbase[i] = table_start[(long long)i * s.nchunks + chunk];
+    lstart[i] = 0;
+  }
+  __syncthreads();
+  const long long base = chunk * NB_CHUNK;
+  unsigned key[NB_ITEMS], rk[NB_ITEMS];
+  float4 rec[NB_ITEMS];
+  bool ok[NB_ITEMS];
+#pragma unroll
+  for (int k = 0; k < NB_ITEMS; ++k) {
+    const long long i = base + (long long)k * NB_THREADS + threadIdx.x;
+    ok[k] = i < np;
+    if (ok[k]) {
+      key[k] = keys[i];
+      rec[k] = make_float4((float)pos[i * 3 + 0], (float)pos[i * 3 + 1], (float)pos[i * 3 + 2], __int_as_float((int)i));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NB_ITEMS; ++k)
+    if (ok[k]) rk[k] = atomicAdd(&lstart[key[k] >> s.gshift], 1u);
+  __syncthreads();
+  const unsigned total = nb_block_scan(lstart, s.ngroups, scratch);
+#pragma unroll
+  for (int k = 0; k < NB_ITEMS; ++k)
+    if (ok[k]) {
+      const unsigned grp = key[k] >> s.gshift;
+      const unsigned p_ = lstart[grp] + rk[k];
+      gdest[p_] = gbase[grp] + rk[k];
+      stage[p_] = rec[k];
+      skey[p_] = key[k];
+    }
+  __syncthreads();
+  for (unsigned t = threadIdx.x; t < total; t += NB_THREADS) {
+    const unsigned d = gdest[t];
+    rec1[d] = stage[t];
+    key1[d] = skey[t];
+  }
+}
+
+__global__ void __launch_bounds__(NB_THREADS)
+    nb_fine_kernel(const float4* __restrict__ rec1, const unsigned* __restrict__ key1, NbGeom s,
+                   const unsigned* __restrict__ table_start, unsigned* __restrict__ start, float4* __restrict__ srec) {
+  extern __shared__ unsigned nb_lds[];          // [G] counts -> cursors, then scan scratch
+  const int G = 1 << s.gshift;
+  unsigned* cur = nb_lds;
+  unsigned* scratch = nb_lds + G;
+  const int grp = blockIdx.x;
+  const unsigned gs = table_start[(long long)grp * s.nchunks];
+  const unsigned ge = table_start[(long long)(grp + 1) * s.nchunks];   // [ngroups * nchunks] = total
+  for (int i = threadIdx.x; i < G; i += NB_THREADS) cur[i] = 0;
+  __syncthreads();
+  constexpr int U = 4;   // loads of U strides are issued together: the sweeps are latency bound otherwise
+  for (unsigned j0 = gs + threadIdx.x; j0 < ge; j0 += U * NB_THREADS) {
+    unsigned key[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned j = j0 + u * NB_THREADS;
+      key[u] = j < ge ? key1[j] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (key[u] != 0xffffffffu) atomicAdd(&cur[key[u] & (G - 1)], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of the G counters, NB_THREADS * 4 at a time (G <= 32768 = 8 rounds)
+  unsigned carry = 0;
+  for (int c0 = 0; c0 < G; c0 += 4 * NB_THREADS) {
+    const int n = min(4 * NB_THREADS, G - c0);
+    const unsigned tot = nb_block_scan(cur + c0, n, scratch);
+    for (int f = threadIdx.x; f < n; f += NB_THREADS) {
+      const unsigned at = gs + carry + cur[c0 + f];
+      cur[c0 + f] = at;
+      const long long cell = (long long)grp * G + c0 + f;
+      if (cell < s.ncell) start[cell] = at;
+    }
+    carry += tot;
+    __syncthreads();
+  }
+  if (grp == s.ngroups - 1 && threadIdx.x == 0) start[s.ncell] = ge;
+  __syncthreads();
+  for (unsigned j0 = gs + threadIdx.x; j0 < ge; j0 += U * NB_THREADS) {
+    unsigned key[U];
+    float4 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned j = j0 + u * NB_THREADS;
+      key[u] = 0xffffffffu;
+      if (j < ge) {
+        key[u] = key1[j];
+        r[u] = rec1[j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (key[u] != 0xffffffffu) srec[atomicAdd(&cur[key[u] & (G - 1)], 1u)] = r[u];
+  }
 }
 
 // One thread per lattice point.  The cell columns that rings 0 and 1 of every point of a
@@ -1337,9 +1551,11 @@ int nn_grid_side(int64_t np) {
 }
 
 struct NnLayout {
-  size_t header, count, fill, start, tiles, srec, list, list_count, total;
+  size_t header, count, fill, start, tiles, srec, list, list_count, keys, key1, rec1, table, total;
   long long ncell, ntiles;
   int M;
+  bool sorted;      // cell list by the two-level LDS bucket sort (else: counting sort with global atomics)
+  NbGeom nb;
 };
 
 NnLayout nn_layout(int64_t np, int /*is_f64*/, int64_t nq_slab) {
@@ -1357,6 +1573,24 @@ NnLayout nn_layout(int64_t np, int /*is_f64*/, int64_t nq_slab) {
   l.srec = off;   off = align(off + (size_t)np * sizeof(float4));
   l.list_count = off; off = align(off + sizeof(unsigned));
   l.list = off;   off = align(off + (size_t)(nq_slab > 0 ? nq_slab : 0) * sizeof(unsigned));   // unresolved points of the scatter pass
+  // two-level sort: groups of 2^gshift cells, as few as keep a group's counters inside LDS
+  NbGeom& nb = l.nb;
+  nb.ncell = l.ncell;
+  nb.nchunks = (np + NB_CHUNK - 1) / NB_CHUNK;
+  nb.gshift = 0;
+  while (nb.gshift < NB_MAXG_SHIFT && ((l.ncell + (1LL << nb.gshift) - 1) >> nb.gshift) > 512) ++nb.gshift;
+  nb.ngroups = (int)((l.ncell + (1LL << nb.gshift) - 1) >> nb.gshift);
+  l.sorted = np >= 4 * NB_CHUNK && nb.ngroups <= NB_MAXGROUPS && vps_option("nn_build_atomic", 0) == 0;
+  l.keys = l.key1 = l.rec1 = l.table = off;
+  if (l.sorted) {
+    const long long nt = (long long)nb.ngroups * nb.nchunks;
+    l.keys = off;  off = align(off + (size_t)np * sizeof(unsigned));
+    l.key1 = off;  off = align(off + (size_t)np * sizeof(unsigned));
+    l.rec1 = off;  off = align(off + (size_t)np * sizeof(float4));
+    l.table = off; off = align(off + (size_t)(nt + 1) * sizeof(unsigned));
+    if ((size_t)(scan_tiles(nt) + 1) > (size_t)(l.ntiles + 1))     // the scan's tile scratch is shared with the cell scan's
+      l.sorted = false;
+  }
   l.total = off;
   return l;
 }
@@ -1421,9 +1655,30 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
   // bound on |float32 distance - exact distance|: each coordinate is rounded to float32 once
   // (relative 2^-24) on both sides of the subtraction, three components
   const float err = (float)((qmax + pmax) * 2.5e-7);
-  VPS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, sizeof(unsigned) * l.ncell, ctx->stream));
-  VPS_HIP_CHECK(ctx, hipMemsetAsync(fill, 0, sizeof(unsigned) * l.ncell, ctx->stream));
-  {
+  if (l.sorted) {
+    const NbGeom& nb = l.nb;
+    unsigned* keys = reinterpret_cast<unsigned*>(work + l.keys);
+    unsigned* key1 = reinterpret_cast<unsigned*>(work + l.key1);
+    float4* rec1 = reinterpret_cast<float4*>(work + l.rec1);
+    unsigned* table = reinterpret_cast<unsigned*>(work + l.table);
+    const size_t lds_h = sizeof(unsigned) * nb.ngroups;
+    const size_t lds_s = sizeof(unsigned) * ((size_t)NB_CHUNK * 6 + 2 * nb.ngroups + NB_THREADS / 64);
+    const size_t lds_f = sizeof(unsigned) * ((1u << nb.gshift) + NB_THREADS / 64);
+    auto ks = nb_scatter_kernel<F>;
+    VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    if (lds_f > 64 * 1024)
+      VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nb_fine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+    vps_launch_timer tm(ctx, VPS_K_NN_BUILD);
+    hipLaunchKernelGGL(nb_hist_kernel<F>, dim3((unsigned)nb.nchunks), dim3(NB_THREADS), lds_h, ctx->stream, pos, (long long)np, g, nb,
+                       keys, table);
+    launch_exclusive_scan(ctx->stream, table, (long long)nb.ngroups * nb.nchunks, tiles, table);   // in place
+    const unsigned sgrid = (unsigned)(((nb.nchunks + 7) / 8) * 8);
+    hipLaunchKernelGGL(ks, dim3(sgrid), dim3(NB_THREADS), lds_s, ctx->stream, pos, (long long)np, keys, nb, table, rec1, key1);
+    hipLaunchKernelGGL(nb_fine_kernel, dim3((unsigned)nb.ngroups), dim3(NB_THREADS), lds_f, ctx->stream, rec1, key1, nb, table, start,
+                       srec);
+  } else {
+    VPS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, sizeof(unsigned) * l.ncell, ctx->stream));
+    VPS_HIP_CHECK(ctx, hipMemsetAsync(fill, 0, sizeof(unsigned) * l.ncell, ctx->stream));
     vps_launch_timer tm(ctx, VPS_K_NN_BUILD);
     hipLaunchKernelGGL(nn_count_kernel<F>, dim3(pblocks), dim3(256), 0, ctx->stream, pos, (long long)np, g, count);
     launch_exclusive_scan(ctx->stream, count, l.ncell, tiles, start);

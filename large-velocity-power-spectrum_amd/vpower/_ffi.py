@@ -187,7 +187,7 @@ def lib():
 # Switches of the library (include/vps_hip.h: vps_set_option).  The library itself never reads the environment; the
 # variables VPS_OPT_<NAME> (e.g. VPS_OPT_NN_KAPPA=1.3) are mapped ONCE, here, and recorded in OPTIONS so that a run can
 # report them.
-OPTION_NAMES = ("no_fast_binning", "no_pair_binning", "nn_query_centric", "nn_column", "nn_kappa", "nn_stats", "sort_groups",
+OPTION_NAMES = ("no_fast_binning", "no_pair_binning", "nn_query_centric", "nn_column", "nn_build_atomic", "nn_kappa", "nn_stats", "sort_groups",
                 "sort_staged", "sort_atomic", "nn_ablate")
 OPTIONS = {}
 

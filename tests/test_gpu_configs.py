@@ -493,6 +493,10 @@ def test_nn_scatter_and_query_centric_kernels_agree(K):
     with _ffi.option("nn_query_centric", 1):
         _, i2 = K.nn_resample(dpos, payload, (ax, ax, ax), 0, N, want_index=True)
     assert np.array_equal(i1.cpu().numpy().ravel(), ref) and np.array_equal(i2.cpu().numpy().ravel(), ref)
+    # the cell list by the counting sort with global atomics instead of the two-level LDS bucket sort (Np >= 16384 takes the latter)
+    with _ffi.option("nn_build_atomic", 1):
+        _, i1a = K.nn_resample(dpos, payload, (ax, ax, ax), 0, N, want_index=True)
+    assert np.array_equal(i1a.cpu().numpy().ravel(), ref)
     # the two uniform-lattice kernels, each forced: column-register search (lanes own z-columns, no atomics) and
     # particle-centric scatter (LDS minima); with a payload, so that the fused epilogues are compared too
     pay4 = K.to_device(rng.standard_normal((Np, 4)).astype(np.float32))
