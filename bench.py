@@ -145,8 +145,13 @@ class Workload:
         self.acc_buf = self.pipe._acc_buf
         nx = self.nx
         maxc = max(NCOMP[q] for q in self.quantities)
+        self.slab_particles = None
         if route == "ngp":
             self.fused = (not unfused) and all(K.fused_supported(N, device.QUANTITY[q]) for q in self.quantities)
+            if self.fused and self.pipe.chunked and nx < N:
+                # a rank holds the whole (replicated) particle set but sorts only those inside its slab: the workspace is
+                # sized for them (counted once, outside the timed region; 1 % head room for nothing -- the count is exact)
+                self.slab_particles = K.count_in_slab(pos, N, L, self.x0, nx)
             # Several ranks, several quantities: the quantities are pipelined -- quantity q+1's deposit + z pass is issued while
             # q's chunks are still crossing the node, q's x passes run after it.  Needs a z image per quantity and two
             # quantities' send / receive buffers at a time: on from 4 ranks (2 ranks of C4 would need > 288 GB), or
@@ -206,7 +211,7 @@ class Workload:
             def producer(i, q):
                 def produce():
                     z = K.deposit_fft_z(self.pos, self.vel, self.rho, N, L, x0, nx, dev.QUANTITY[q], zimg=self.zimg_q[i],
-                                        reuse_sort=state["token"])
+                                        reuse_sort=state["token"], slab_particles=self.slab_particles)
                     state["token"] = K.fused_token()
                     return [z[c] for c in range(NCOMP[q])]
                 return produce
@@ -227,7 +232,8 @@ class Workload:
                 self.acc_buf.zero_()
                 if self.fused and self.pipe.chunked:
                     # several ranks: the fused kernel stops after the z pass; y pass, exchange and x pass run chunk by chunk
-                    z = K.deposit_fft_z(self.pos, self.vel, self.rho, N, L, x0, nx, qi, zimg=self.zimg[:nc], reuse_sort=token)
+                    z = K.deposit_fft_z(self.pos, self.vel, self.rho, N, L, x0, nx, qi, zimg=self.zimg[:nc], reuse_sort=token,
+                                        slab_particles=self.slab_particles)
                     token = K.fused_token()
                     self.pipe.accumulate_zimages([z[i] for i in range(nc)], self.psum, self.nsample)
                 elif self.fused:

@@ -137,7 +137,7 @@ int vps_deposit_field(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const f
                       int quantity, int flags, float* fields_dev, void* work_dev);
 
 /* The shortest form of stages A1 + A3 + the z and y passes of B (VPS_VELOCITY, VPS_MOMENTUM,
- * VPS_ENERGY; N in [64, 2048]): particle records are bucketed by "pencil" (one z-pass tile:
+ * VPS_ENERGY; N in [64, 4096]): particle records are bucketed by "pencil" (one z-pass tile:
  * x, 16 y-lines, all z), each pencil is accumulated in LDS, turned into v = rho v / rho (or p, or
  * E = m |v|^2) and transformed along z without the real-space grid ever touching HBM; then the
  * y pass.  Outputs, per component c (3 for velocity / momentum, 1 for energy), the arrays
@@ -274,6 +274,19 @@ size_t vps_deposit_fft_z_workspace_bytes(int64_t np, int N, int nx);
 int vps_deposit_fft_z(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
                       const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx,
                       int quantity, int flags, void* zimg_dev, void* work_dev);
+/* Ranks that hold a REPLICATED particle set but deposit one x-slab of it (scripts/parallel_optimized.py:272-276 loads the whole
+ * snapshot on every rank): the sort workspace sized for the particles INSIDE the slab instead of all np --
+ *   vps_count_in_slab                       that number, with the deposit's own bit-exact cell rule (one pass over the
+ *                                           positions, blocks; < 0: error);
+ *   vps_deposit_fft_z_workspace_bytes_slab  workspace for np particles of which at most np_slab lie in the slab: no per-input
+ *                                           key array, record arrays of np_slab entries (C5 on 8 ranks: 52 GB -> 6 GB);
+ *   vps_deposit_fft_z_slab                  vps_deposit_fft_z on such a workspace; VPS_ERR_ARG if more than np_slab particles
+ *                                           turn out to lie inside (checked before anything is written past the bound). */
+int64_t vps_count_in_slab(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, int64_t np, int N, double Lbox, int x0, int nx);
+size_t vps_deposit_fft_z_workspace_bytes_slab(int64_t np, int64_t np_slab, int N, int nx);
+int vps_deposit_fft_z_slab(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
+                           const float* rho_dev, int64_t np, int64_t np_slab, int N, double Lbox, int x0, int nx,
+                           int quantity, int flags, void* zimg_dev, void* work_dev);
 int64_t vps_fft_y_chunk_elems(int N, int nx, int G, int nchunks, int chunk);   /* -1: G, nchunks do not divide */
 int vps_fft_y_packed(vps_ctx* ctx, int N);   /* 1: vps_fft_y packs rows now (binning-only scope with a row cut for N) */
 int64_t vps_fft_y_chunk_block(vps_ctx* ctx, int N, int nx, int G, int nchunks, int chunk, int packed);   /* pure size query (host tables only). -1: bad arguments, -2: G x nchunks does not divide N/2, -3: packed without a row cut (vps_last_error says which) */

@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(SORT_THREADS)
         key = (K)brick * g.cells + loc;
         atomicAdd(&sort_lds[brick >> g.gshift], 1u);
       }
-      keys[i] = key;
+      if (keys) keys[i] = key;     // (NULL: the scatter pass locates the particles again -- slab-sized workspaces)
     }
   }
   __syncthreads();
@@ -364,11 +364,15 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned* a, int n, uns
 // of 64 scattered dwords per instruction.  Consecutive chunks own adjacent runs of every group:
 // they are dealt to the SAME XCD (blockIdx % 8, speed only) so that its L2 can merge the partly
 // written lines at run boundaries.
-template <int C, bool RHOV, typename K>
+// RECOMP: there is no keys[] array (8 bytes per INPUT particle -- 8 GB of a rank's workspace at 1e9 replicated particles of
+// which an eighth lie in its slab): the particles are located again from their positions, which costs the same 12 bytes of
+// reads that the keys cost 8 of.
+template <int C, bool RHOV, typename K, typename F, bool RECOMP>
 __global__ void __launch_bounds__(SORT_THREADS)
     sort_scatter_staged_kernel(const K* __restrict__ keys, const float* __restrict__ payload,
                                const float* __restrict__ rho, long long np, SortGeom g,
-                               const unsigned* __restrict__ table_start, unsigned* __restrict__ rec1) {
+                               const unsigned* __restrict__ table_start, unsigned* __restrict__ rec1,
+                               const F* __restrict__ pos, F lcell, F nsize, Bricks b) {
   constexpr int W = sort_rec1_words(C);
   extern __shared__ unsigned sort_lds[];
   unsigned* gbase = sort_lds;                        // [ngroups] first global slot of this chunk's run
@@ -391,7 +395,12 @@ __global__ void __launch_bounds__(SORT_THREADS)
 #pragma unroll
   for (int k = 0; k < SORT_ITEMS; ++k) {
     const long long i = base + (long long)k * SORT_THREADS + threadIdx.x;
-    key[k] = (i < np) ? keys[i] : sort_invalid<K>();
+    if constexpr (RECOMP) {
+      unsigned brick, loc;
+      key[k] = (i < np && locate<F>(pos, i, lcell, nsize, b, brick, loc)) ? (K)brick * g.cells + loc : sort_invalid<K>();
+    } else {
+      key[k] = (i < np) ? keys[i] : sort_invalid<K>();
+    }
     if (key[k] != sort_invalid<K>()) load_payload<C, RHOV>(payload, rho, i, val[k]);
   }
 #pragma unroll
@@ -777,6 +786,8 @@ Bricks make_pencils(int N, int x0, int nx, int TP) {
 struct DepLayout {
   size_t count, start, tiles, keys, ranks, records, table, table_start, table_tiles, rec1, total;
   long long nbricks;
+  long long cap;    // records the workspace has room for: np, or the caller's bound on the particles inside the slab
+  bool recompute;   // cap < np: no keys[] array either (sort_scatter_staged_kernel<..., RECOMP>)
   bool two_level;
   bool wide_keys;   // bucket * cells + cell does not fit 32 bits: 64-bit keys[] (the level-1 records stay 32-bit, see SortGeom)
   SortGeom geom;
@@ -796,7 +807,13 @@ bool sort_staged() { return vps_option("sort_staged", 1) != 0; }
 // two-level sort does not cover, and as a cross-check in the tests)
 bool sort_force_atomic() { return vps_option("sort_atomic", 0) != 0; }
 
-DepLayout dep_layout(int64_t np, int C, const Bricks& b) {
+size_t sort_staged_lds(const SortGeom& g, int C) {
+  return sizeof(unsigned) * (2 * (size_t)g.ngroups + SORT_THREADS / 64 + (size_t)SORT_CHUNK * (1 + sort_rec1_words(C)));
+}
+
+// np_cap >= 0: the caller's bound on the number of particles inside the slab (vps_count_in_slab): the record arrays are sized
+// for it and the key array disappears -- for ranks that hold a replicated particle set but deposit one slab of it
+DepLayout dep_layout(int64_t np, int C, const Bricks& b, int64_t np_cap = -1) {
   DepLayout l;
   l.nbricks = (long long)b.nbx * b.nby * b.nbz;
   SortGeom& g = l.geom;
@@ -815,20 +832,22 @@ DepLayout dep_layout(int64_t np, int C, const Bricks& b) {
   l.two_level = !sort_force_atomic() && g.gshift <= 12 && l.nbricks < 0x7fffffffLL &&
                 ((unsigned long long)b.cells << g.gshift) < 0xffffffffull;
   const long long ntable = (long long)g.ngroups * g.nchunks;
+  l.recompute = np_cap >= 0 && np_cap < np && l.two_level && sort_staged() && sort_staged_lds(g, C) <= 160 * 1024;
+  l.cap = l.recompute ? np_cap : np;
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t off = 0;
   l.count = off;   off = align(off + sizeof(unsigned) * l.nbricks);
   l.start = off;   off = align(off + sizeof(unsigned) * (l.nbricks + 1));
   l.tiles = off;   off = align(off + sizeof(unsigned) * (scan_tiles(l.nbricks) + 1));
-  l.keys = off;    off = align(off + (size_t)np * sizeof(unsigned long long));
-  l.ranks = off;   off = align(off + (size_t)np * sizeof(unsigned));
-  l.records = off; off = align(off + (size_t)np * (C + 1) * sizeof(unsigned));
+  l.keys = off;    off = align(off + (l.recompute ? 0 : (size_t)np * sizeof(unsigned long long)));
+  l.ranks = off;   off = align(off + (size_t)l.cap * sizeof(unsigned));
+  l.records = off; off = align(off + (size_t)l.cap * (C + 1) * sizeof(unsigned));
   l.table = l.table_start = l.table_tiles = l.rec1 = off;
   if (l.two_level) {
     l.table = off;        off = align(off + sizeof(unsigned) * (ntable + 1));
     l.table_start = off;  off = align(off + sizeof(unsigned) * (ntable + 1));
     l.table_tiles = off;  off = align(off + sizeof(unsigned) * (scan_tiles(ntable) + 1));
-    l.rec1 = off;         off = align(off + (size_t)np * sort_rec1_words(C) * sizeof(unsigned));
+    l.rec1 = off;         off = align(off + (size_t)l.cap * sort_rec1_words(C) * sizeof(unsigned));
   }
   l.total = off;
   return l;
@@ -854,22 +873,37 @@ int sort_into_buckets(vps_ctx* ctx, const F* pos, const float* payload, const fl
     unsigned* rec1 = reinterpret_cast<unsigned*>(work + l.rec1);
     const size_t lds1 = sizeof(unsigned) * g.ngroups;
     const size_t lds2 = sizeof(unsigned) * ((1u << g.gshift) + FINE_THREADS / 64);
-    const size_t lds_staged = sizeof(unsigned) * (2 * (size_t)g.ngroups + SORT_THREADS / 64 +
-                                                   (size_t)SORT_CHUNK * (1 + sort_rec1_words(C)));
+    const size_t lds_staged = sort_staged_lds(g, C);
     const bool staged = sort_staged() && lds_staged <= ctx->lds_per_cu;
+    if (l.recompute && !staged) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "slab-sized sort workspace needs the LDS-staged scatter");
     auto level1 = [&](auto* keys) -> int {
       typedef typename std::remove_pointer<decltype(keys)>::type K;
       hipLaunchKernelGGL((sort_hist_kernel<F, K>), dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1, ctx->stream, pos,
-                         (long long)np, lcell, nsz, b, g, keys, table);
+                         (long long)np, lcell, nsz, b, g, l.recompute ? (K*)nullptr : keys, table);
       launch_exclusive_scan(ctx->stream, table, (long long)g.ngroups * g.nchunks, table_tiles, table_start);
+      if (l.recompute) {
+        // the scan's total is the number of particles inside the slab: it must fit the caller's bound
+        unsigned inside = 0;
+        VPS_HIP_CHECK(ctx, hipMemcpyAsync(&inside, table_start + (long long)g.ngroups * g.nchunks, sizeof(unsigned),
+                                          hipMemcpyDeviceToHost, ctx->stream));
+        VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if ((long long)inside > l.cap)
+          return vps_fail(ctx, VPS_ERR_ARG, "%u particles lie inside the slab, the workspace was sized for %lld (vps_count_in_slab)",
+                          inside, l.cap);
+      }
       if (staged) {
-        auto kern = sort_scatter_staged_kernel<C, RHOV, K>;
-        if (lds_staged > 64 * 1024)
-          VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
         const unsigned grid = (unsigned)(8 * ((g.nchunks + 7) / 8));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(SORT_THREADS), lds_staged, ctx->stream, keys, payload, rho,
-                           (long long)np, g, table_start, rec1);
+        auto go = [&](auto kern) -> int {
+          if (lds_staged > 64 * 1024)
+            VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
+          hipLaunchKernelGGL(kern, dim3(grid), dim3(SORT_THREADS), lds_staged, ctx->stream, (const K*)keys, payload, rho,
+                             (long long)np, g, table_start, rec1, pos, lcell, nsz, b);
+          return VPS_OK;
+        };
+        const int rcs = l.recompute ? go(sort_scatter_staged_kernel<C, RHOV, K, F, true>)
+                                    : go(sort_scatter_staged_kernel<C, RHOV, K, F, false>);
+        if (rcs) return rcs;
       } else {
         hipLaunchKernelGGL((sort_scatter_kernel<C, RHOV, K>), dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1,
                            ctx->stream, keys, payload, rho, (long long)np, g, table_start, rec1);
@@ -938,11 +972,24 @@ int deposit_run(vps_ctx* ctx, const void* pos_v, const float* payload, const flo
 // rank -> scan -> scatter of [rho v, rho] records into the buckets `b`; returns the layout used
 template <typename F>
 int sort_rhov_records(vps_ctx* ctx, const F* pos, const float* vel, const float* rho, int64_t np, int N,
-                      double Lbox, const Bricks& b, char* work, DepLayout* lay) {
+                      double Lbox, const Bricks& b, char* work, DepLayout* lay, int64_t np_cap = -1) {
   const F lcell = (F)(Lbox / (double)N);
   const F nsz = (F)N;
-  *lay = dep_layout(np, 4, b);
+  *lay = dep_layout(np, 4, b, np_cap);
   return sort_into_buckets<F, 4, true>(ctx, pos, vel, rho, np, lcell, nsz, b, *lay, work);
+}
+
+// particles whose bit-exact cell lies inside the slab (the rule of `locate`)
+template <typename F>
+__global__ void __launch_bounds__(256) count_in_slab_kernel(const F* __restrict__ pos, long long np, F lcell, F nsize, Bricks b,
+                                                            unsigned long long* __restrict__ out) {
+  unsigned n = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (long long)gridDim.x * blockDim.x) {
+    unsigned brick, loc;
+    n += locate<F>(pos, i, lcell, nsize, b, brick, loc) ? 1u : 0u;
+  }
+  for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, (unsigned long long)n);
 }
 
 int check_deposit_args(vps_ctx* ctx, const char* who, int64_t np, int N, double Lbox, int x0, int nx) {
@@ -1038,7 +1085,7 @@ size_t vps_deposit_fft_zy_workspace_bytes(int64_t np, int N, int nx) {
 
 static int deposit_fft_impl(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
                             const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx, int quantity,
-                            int flags, void* spec_dev, void* nyq_dev, void* zimg_dev, void* work_dev);
+                            int flags, void* spec_dev, void* nyq_dev, void* zimg_dev, void* work_dev, int64_t np_cap = -1);
 
 int vps_deposit_fft_zy(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
                        const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx, int quantity,
@@ -1063,10 +1110,54 @@ int vps_deposit_fft_z(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const f
                           nullptr, zimg_dev, work_dev);
 }
 
+int64_t vps_count_in_slab(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, int64_t np, int N, double Lbox, int x0, int nx) {
+  if (!ctx) return VPS_ERR_ARG;
+  vps_device_guard guard(ctx);
+  int rc = check_deposit_args(ctx, "vps_count_in_slab", np, N, Lbox, x0, nx);
+  if (rc) return rc;
+  if (np == 0) return 0;
+  if (!pos_dev) return vps_fail(ctx, VPS_ERR_ARG, "vps_count_in_slab: null buffer");
+  const Bricks b = make_pencils(N, x0, nx, 1);
+  unsigned long long* d = nullptr;
+  VPS_HIP_CHECK(ctx, hipMalloc(&d, sizeof(unsigned long long)));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream);
+  const unsigned grid = (unsigned)std::min<long long>((np + 255) / 256, 4096);
+  if (e == hipSuccess) {
+    if (pos_is_f64)
+      hipLaunchKernelGGL(count_in_slab_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<const double*>(pos_dev),
+                         (long long)np, Lbox / (double)N, (double)N, b, d);
+    else
+      hipLaunchKernelGGL(count_in_slab_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<const float*>(pos_dev),
+                         (long long)np, (float)(Lbox / (double)N), (float)N, b, d);
+    e = hipGetLastError();
+  }
+  unsigned long long h = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return vps_fail(ctx, VPS_ERR_HIP, "vps_count_in_slab: %s", hipGetErrorString(e));
+  return (int64_t)h;
+}
+
+size_t vps_deposit_fft_z_workspace_bytes_slab(int64_t np, int64_t np_slab, int N, int nx) {
+  if (np < 0 || np_slab < 0 || N < 16 || nx < 1) return 0;
+  return dep_layout(np, 4, make_pencils(N, 0, nx, vps_pencil_tp(N)), np_slab).total;
+}
+
+int vps_deposit_fft_z_slab(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
+                           const float* rho_dev, int64_t np, int64_t np_slab, int N, double Lbox, int x0, int nx, int quantity,
+                           int flags, void* zimg_dev, void* work_dev) {
+  VPS_ENTER(ctx);
+  if (!zimg_dev) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_fft_z_slab: null buffer");
+  if (np_slab < 0) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_fft_z_slab: np_slab < 0");
+  return deposit_fft_impl(ctx, pos_dev, pos_is_f64, vel_dev, rho_dev, np, N, Lbox, x0, nx, quantity, flags, nullptr,
+                          nullptr, zimg_dev, work_dev, np_slab);
+}
+
 // zimg_dev != NULL: stop after the z pass, the images [component][B | BN] go to zimg_dev (work_dev then only holds the sort)
 static int deposit_fft_impl(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
                             const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx, int quantity,
-                            int flags, void* spec_dev, void* nyq_dev, void* zimg_dev, void* work_dev) {
+                            int flags, void* spec_dev, void* nyq_dev, void* zimg_dev, void* work_dev, int64_t np_cap) {
   int rc = check_deposit_args(ctx, "vps_deposit_fft_zy", np, N, Lbox, x0, nx);
   if (rc) return rc;
   if (!vps_deposit_fft_zy_supported(ctx, N, quantity))
@@ -1077,10 +1168,10 @@ static int deposit_fft_impl(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, c
   char* work = reinterpret_cast<char*>(work_dev);
   DepLayout l;
   if (flags & VPS_FLAG_REUSE_SORT) {
-    l = dep_layout(np, 4, b);     // the caller vouches that the records of the previous call are still there
+    l = dep_layout(np, 4, b, np_cap);     // the caller vouches that the records of the previous call are still there
   } else {
-    rc = pos_is_f64 ? sort_rhov_records<double>(ctx, reinterpret_cast<const double*>(pos_dev), vel_dev, rho_dev, np, N, Lbox, b, work, &l)
-                    : sort_rhov_records<float>(ctx, reinterpret_cast<const float*>(pos_dev), vel_dev, rho_dev, np, N, Lbox, b, work, &l);
+    rc = pos_is_f64 ? sort_rhov_records<double>(ctx, reinterpret_cast<const double*>(pos_dev), vel_dev, rho_dev, np, N, Lbox, b, work, &l, np_cap)
+                    : sort_rhov_records<float>(ctx, reinterpret_cast<const float*>(pos_dev), vel_dev, rho_dev, np, N, Lbox, b, work, &l, np_cap);
     if (rc) return rc;
   }
   const double lc = Lbox / (double)N;

@@ -1739,7 +1739,7 @@ void build_stage_tw(std::vector<cf>& out) {
 #define VPS_PENCIL_FAMILY_0(CALL)
 #endif
 #if VPS_FFT_PART == -1 || VPS_FFT_PART == 1
-#define VPS_PENCIL_FAMILY_1(CALL) case 512: { constexpr int NC_ = 512; CALL; } break; case 1024: { constexpr int NC_ = 1024; CALL; } break;
+#define VPS_PENCIL_FAMILY_1(CALL) case 512: { constexpr int NC_ = 512; CALL; } break; case 1024: { constexpr int NC_ = 1024; CALL; } break; case 2048: { constexpr int NC_ = 2048; CALL; } break;
 #else
 #define VPS_PENCIL_FAMILY_1(CALL)
 #endif
@@ -2142,7 +2142,7 @@ static int fft_y_of(vps_ctx* ctx, int N, int nx, const cf* B, const cf* BN, void
 int vps_pencil_tp(int N) { return N / 2 >= 1024 ? VPS_PENCIL_TP_LONG : 16; }   // = pencil_tp<N/2>()
 
 bool vps_pencil_supported(vps_ctx* ctx, int N) {
-  if (!vps_fft_supported(N) || N < 64 || N > 2048) return false;
+  if (!vps_fft_supported(N) || N < 64 || N > 4096) return false;   // (4096: 8-line pencils of 2048 packed points on 1024 threads, 148 KB of LDS)
   const long long lds = route_pencil_lds(N / 2);
   if (lds < 0) return false;
   return (size_t)lds <= ctx->lds_per_cu;

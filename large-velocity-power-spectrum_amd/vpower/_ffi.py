@@ -74,6 +74,10 @@ SYMBOLS = (
     ("vps_deposit_fft_z_workspace_bytes", C.c_size_t, (_i64, C.c_int, C.c_int)),
     ("vps_deposit_fft_z", C.c_int, (_vp, _vp, C.c_int, _vp, _vp, _i64, C.c_int, C.c_double, C.c_int, C.c_int,
                                     C.c_int, C.c_int, _vp, _vp)),
+    ("vps_count_in_slab", _i64, (_vp, _vp, C.c_int, _i64, C.c_int, C.c_double, C.c_int, C.c_int)),
+    ("vps_deposit_fft_z_workspace_bytes_slab", C.c_size_t, (_i64, _i64, C.c_int, C.c_int)),
+    ("vps_deposit_fft_z_slab", C.c_int, (_vp, _vp, C.c_int, _vp, _vp, _i64, _i64, C.c_int, C.c_double, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, _vp, _vp)),
     ("vps_fft_y_chunk_elems", _i64, (C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)),
     ("vps_fft_y_packed", C.c_int, (_vp, C.c_int)),
     ("vps_fft_y_chunk_block", _i64, (_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)),

@@ -308,14 +308,14 @@ class HipKernels:
                                               self._ptr(spec), self._ptr(nyq), self._ptr(work)))
         return spec, nyq
 
-    def _reuse_flag(self, reuse_sort, pos, vel, rho, N, Lbox, x0, nx, work):
+    def _reuse_flag(self, reuse_sort, pos, vel, rho, N, Lbox, x0, nx, work, cap=None):
         """FLAG_REUSE_SORT if `reuse_sort` (a token returned by an earlier fused call) proves that the bucketed records
         of that call are still in `work`: several quantities of the SAME particle tensors then sort only once.  The
         token holds WEAK references to the tensors (a freed tensor whose address is recycled cannot pass for the old
         one, and nothing is kept alive by the library) and their in-place modification counters; any mismatch silently
         sorts again.  Records the token of THIS call."""
         state = (weakref.ref(pos), weakref.ref(vel), weakref.ref(rho), pos._version, vel._version, rho._version,
-                 int(N), float(Lbox), int(x0), int(nx), work.data_ptr())
+                 int(N), float(Lbox), int(x0), int(nx), work.data_ptr(), cap)
         last = getattr(self, "_fused_token", None)
         ok = (reuse_sort is not None and reuse_sort is last
               and all(r() is t for r, t in zip(last[:3], (pos, vel, rho))) and last[3:] == state[3:])
@@ -451,18 +451,38 @@ class HipKernels:
                                      self._ptr(zimg, torch.complex64)))
         return zimg
 
-    def deposit_fft_z(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, zimg=None, reuse_sort=None):
-        """Fused deposit + field algebra + z pass -> z images [ncomp, zimage_elems] (ncomp = 1 for ENERGY, else 3)."""
+    def count_in_slab(self, pos, N, Lbox, x0, nx):
+        """Particles whose (bit-exact) cell lies in the x-slab [x0, x0 + nx) (vps_count_in_slab)."""
+        self._stream()
+        n = int(self.lib.vps_count_in_slab(self.ctx, self._ptr(pos), self._pos_kind(pos), pos.shape[0], int(N), float(Lbox),
+                                           int(x0), int(nx)))
+        if n < 0:
+            self._chk(n)
+        return n
+
+    def deposit_fft_z(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, zimg=None, reuse_sort=None, slab_particles=None):
+        """Fused deposit + field algebra + z pass -> z images [ncomp, zimage_elems] (ncomp = 1 for ENERGY, else 3).
+        slab_particles: a bound on the particles inside the slab (count_in_slab): the sort workspace is then sized for it,
+        not for all of a replicated particle set."""
         self._stream()
         ncomp = 1 if quantity == ENERGY else 3
         if zimg is None:
             zimg = self.empty((ncomp, self.zimage_elems(N, nx)), torch.complex64)
-        work = self.workspace("fused_z", self.lib.vps_deposit_fft_z_workspace_bytes(pos.shape[0], N, nx))
-        flags |= self._reuse_flag(reuse_sort, pos, vel, rho, N, Lbox, x0, nx, work)
-        self._chk(self.lib.vps_deposit_fft_z(self.ctx, self._ptr(pos), self._pos_kind(pos),
-                                             self._ptr(vel, torch.float32), self._ptr(rho, torch.float32),
-                                             pos.shape[0], N, float(Lbox), x0, nx, quantity, flags,
-                                             self._ptr(zimg, torch.complex64), self._ptr(work)))
+        if slab_particles is None:
+            work = self.workspace("fused_z", self.lib.vps_deposit_fft_z_workspace_bytes(pos.shape[0], N, nx))
+        else:
+            work = self.workspace("fused_z", self.lib.vps_deposit_fft_z_workspace_bytes_slab(pos.shape[0], int(slab_particles), N, nx))
+        flags |= self._reuse_flag(reuse_sort, pos, vel, rho, N, Lbox, x0, nx, work, slab_particles)
+        if slab_particles is None:
+            self._chk(self.lib.vps_deposit_fft_z(self.ctx, self._ptr(pos), self._pos_kind(pos),
+                                                 self._ptr(vel, torch.float32), self._ptr(rho, torch.float32),
+                                                 pos.shape[0], N, float(Lbox), x0, nx, quantity, flags,
+                                                 self._ptr(zimg, torch.complex64), self._ptr(work)))
+        else:
+            self._chk(self.lib.vps_deposit_fft_z_slab(self.ctx, self._ptr(pos), self._pos_kind(pos),
+                                                      self._ptr(vel, torch.float32), self._ptr(rho, torch.float32),
+                                                      pos.shape[0], int(slab_particles), N, float(Lbox), x0, nx, quantity, flags,
+                                                      self._ptr(zimg, torch.complex64), self._ptr(work)))
         return zimg
 
     def y_chunk_elems(self, N, nx, G, nchunks, chunk):

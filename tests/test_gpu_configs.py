@@ -146,10 +146,11 @@ def _ngp_moments_float64(K, dpos, dvel, drho, N, L, quantities, rows=128):
 # ------------------------------------------- fused deposit + z/y passes, full-size lines ----
 @pytest.mark.parametrize("N,nx,x0,quantity", [(512, 16, 96, "velocity"), (512, 16, 496, "momentum"), (1024, 16, 512, "velocity"),
                                                (1024, 16, 0, "energy"), (2048, 16, 1200, "velocity"),
-                                               (2048, 16, 2032, "momentum"), (2048, 16, 16, "energy")])
+                                               (2048, 16, 2032, "momentum"), (2048, 16, 16, "energy"),
+                                               (4096, 16, 2064, "energy"), (4096, 16, 4080, "velocity")])
 def test_fused_deposit_fft_zy_thin_slab_against_oracle(K, N, nx, x0, quantity):
     """vps_deposit_fft_zy (the kernel pair bench.py times) against numpy's rfft/fft of the
-    ORACLE-deposited slab -- not against another HIP path -- at the line lengths of C2, C3, C4."""
+    ORACLE-deposited slab -- not against another HIP path -- at the line lengths of C2, C3, C4, C5."""
     from vpower import device
     L = 1.0
     rng = np.random.default_rng(N + x0)
@@ -271,7 +272,8 @@ def test_config4_full_size_properties(K):
 # ------------------------------------------------------ C5: one rank's share of 4096^3 ----
 def test_config5_one_rank_share(K):
     """C5 as rank 3 of 8 sees it: 1e9 replicated particles, x-slab of 512 rows of the 4096^3 grid,
-    kinetic-energy field through the un-fused deposit and the 4096-point z / y / x line kernels.
+    kinetic-energy field through the un-fused deposit and the 4096-point z / y / x line kernels, and through the fused
+    deposit + z pass on a slab-sized sort workspace (the route of bench.py).
     Checks: the deposited density of the slab sums to that of the particles whose bit-exact cell
     index (vps_cell_index) falls in the slab; Parseval of the z+y passes; Parseval of
     the segmented x pass + binning over all modes (on the un-exchanged local buffer: any data
@@ -324,7 +326,61 @@ def test_config5_one_rank_share(K):
     got = float(psum.sum().item())
     assert abs(got - 2.0 * N * insq) / (2.0 * N * insq) < 2e-5
     assert int(ns.sum().item()) == 2 * nkz * N * N
-    del spec, nyq, lines
+    del lines
+    # the FUSED route bench.py takes for C5 on several ranks: particles counted into the slab (bit-exact rule), a sort
+    # workspace sized for them (not for the 1e9 replicated ones), fused deposit + z pass at 4096-cell lines, y pass --
+    # against the un-fused spectra above, plane by plane
+    inside = K.count_in_slab(dpos, N, L, x0, nx)
+    n_ref = 0
+    for s in range(0, Np, 50_000_000):
+        e = min(Np, s + 50_000_000)
+        cx = K.cell_index(dpos[s:e], N, L)[:, 0]
+        n_ref += int(((cx >= x0) & (cx < x0 + nx)).sum().item())
+        del cx
+    assert inside == n_ref
+    assert K.fused_supported(N, device.ENERGY)
+    wbytes = int(K.lib.vps_deposit_fft_z_workspace_bytes_slab(Np, inside, N, nx))
+    assert wbytes <= 10 * 2 ** 30 and wbytes < int(K.lib.vps_deposit_fft_z_workspace_bytes(Np, N, nx)) // 4
+    z = K.deposit_fft_z(dpos, dvel, drho, N, L, x0, nx, device.ENERGY, slab_particles=inside)
+    out = K.fft_y_chunk(z[0], N, nx, 1, 1, 0)               # one rank, one chunk: [spec | nyq]
+    del z
+    scale = float(np.sqrt(tot / (N * (N // 2 + 1.0) * nx)))            # rms amplitude of the spectrum
+    ns_ = spec.numel()
+    worst = 0.0
+    step = 64 * N * nx
+    # per mode: 2e-5 of the rms amplitude + 1e-5 of the mode's own (the energy field is positive: its low modes are
+    # thousands of times the rms; both routes are float32 -- E = vol sum q^2 / rho here, m |rho v / rho|^2 there -- summed in
+    # different orders; each is held to 1e-5 of the rms against the float64 oracle by the thin-slab test above)
+    for o in range(0, ns_, step):
+        ref_ = spec.reshape(-1)[o:o + step]
+        worst = max(worst, float(((out[o:o + step] - ref_).abs() - 1e-5 * ref_.abs()).max().item()))
+    worst = max(worst, float(((out[ns_:] - nyq.reshape(-1)).abs() - 1e-5 * nyq.reshape(-1).abs()).max().item()))
+    assert worst / scale < 2e-5, worst / scale
+    del spec, nyq, out
+    _free(K)
+
+
+def test_slab_sized_sort_workspace(K):
+    """vps_count_in_slab + vps_deposit_fft_z_slab: the same z images as the plain call from a workspace sized for the slab's
+    particles only; a bound that is too small is refused before anything is written."""
+    from vpower import device, _ffi
+    N, Np, L, x0, nx = 256, 400_000, 1.0, 96, 32
+    pos, vel, mass, dens = synth(8, Np, L)
+    pos[:1000] = np.nan                                     # never inside any slab
+    d = [K.to_device(a) for a in (pos, vel, dens)]
+    inside = K.count_in_slab(d[0], N, L, x0, nx)
+    cx = orc.cell_index(pos[1000:], N, L)[:, 0]
+    assert inside == int(np.count_nonzero((cx >= x0) & (cx < x0 + nx)))
+    for q in (device.VELOCITY, device.ENERGY):
+        a = K.deposit_fft_z(d[0], d[1], d[2], N, L, x0, nx, q)
+        K._work.clear()
+        b = K.deposit_fft_z(d[0], d[1], d[2], N, L, x0, nx, q, slab_particles=inside)
+        tol = 1e-5 * float(a.abs().square().mean().sqrt().item())
+        assert float((a - b).abs().max().item()) < tol
+    assert int(K.lib.vps_deposit_fft_z_workspace_bytes_slab(Np, inside, N, nx)) < int(K.lib.vps_deposit_fft_z_workspace_bytes(Np, N, nx)) // 3
+    K._work.clear()
+    with pytest.raises(_ffi.VpsError, match="inside the slab"):
+        K.deposit_fft_z(d[0], d[1], d[2], N, L, x0, nx, device.VELOCITY, slab_particles=inside - 1)
     _free(K)
 
 

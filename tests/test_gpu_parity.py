@@ -412,12 +412,12 @@ def test_config1_full_size_against_oracle():
 
 # ------------------------------------------------ fused deposit -> z pass (pencils) ----
 @pytest.mark.parametrize("N,nx,x0", [(64, 64, 0), (128, 128, 0), (128, 32, 64), (256, 256, 0), (512, 64, 448), (1024, 16, 480),
-                                     (2048, 4, 1000), (192, 192, 0), (384, 48, 96), (768, 16, 752), (1536, 8, 8)])
+                                     (2048, 4, 1000), (4096, 2, 3001), (192, 192, 0), (384, 48, 96), (768, 16, 752), (1536, 8, 8)])
 @pytest.mark.parametrize("quantity,flags", [("velocity", 0), ("momentum", 0), ("momentum", 1)])
 def test_fused_deposit_fft_matches_unfused(K, N, nx, x0, quantity, flags):
     from vpower import device
     q = device.QUANTITY[quantity]
-    assert K.fused_supported(N, q) and K.fused_supported(N, device.ENERGY) and not K.fused_supported(4096, q)
+    assert K.fused_supported(N, q) and K.fused_supported(N, device.ENERGY) and K.fused_supported(4096, q) and not K.fused_supported(1000, q)
     rng = np.random.default_rng(N + nx)
     Np = 150000
     pos = rng.random((Np, 3)).astype(np.float32)
