@@ -157,7 +157,7 @@ class Workload:
             # quantities' send / receive buffers at a time: on from 4 ranks (2 ranks of C4 would need > 288 GB), or
             # VPS_PIPELINE_QUANTITIES=1 / 0.
             env = os.environ.get("VPS_PIPELINE_QUANTITIES")
-            self.pipelined = (self.pipe.chunked and len(self.quantities) > 1
+            self.pipelined = (self.pipe.chunked and len(self.quantities) > 1 and not isinstance(comm, device.LibraryComm)
                               and all(K.fused_supported(N, device.QUANTITY[q]) for q in self.quantities) and not unfused
                               and ((comm.world >= 4) if env is None else env == "1"))
             if self.pipelined:
@@ -568,6 +568,10 @@ def main(argv=None):
     from vpower import device, synth
     K = device.default_kernels(local)
     comm = device.SlabComm()
+    if os.environ.get("VPS_BENCH_TRANSPORT") == "library" and world > 1 and backend == "nccl":
+        # the exchange inside libvps_hip.so (vps_spectrum_zimages: RCCL send / recv groups on the library's own stream)
+        # instead of torch.distributed.all_to_all_single; torch only moves the 128-byte id and times the run
+        comm = device.LibraryComm(K)
     if args.emulate_ranks > 1 and world == 1:
         class _OneOfG(device.SlabComm):
             """rank 0 of G without peers: the local z/y output stands in for the exchanged buffer

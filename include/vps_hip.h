@@ -327,6 +327,29 @@ int vps_fft_x_bin_chunk(vps_ctx* ctx, int N, int nx, int G, int nchunks, int chu
                         const void* const* in_devs, int ncomp, int count, double* psum_dev,
                         unsigned long long* nsample_dev);
 
+/* ---- slab exchange inside the library: RCCL over xGMI (one process per GPU) -------------------------------------------
+ * For hosts without a collective of their own (the Python host drives the same chunk pipeline through torch.distributed,
+ * vpower/device.py).  Replaces the four comm.allgather per buffer flush and the two comm.Reduce of
+ * scripts/parallel_optimized.py:365-368, 455-456.  RCCL is loaded at run time (dlopen): VPS_ERR_UNSUPPORTED without it.
+ *   vps_comm_unique_id    rank 0: 128 bytes for the host to hand to every rank (ncclGetUniqueId)
+ *   vps_comm_create       every rank, collectively: ncclCommInitRank on the context's device + a communication stream
+ *   vps_spectrum_zimages  the x-side of the transform of ncomp (1..3) z images (vps_fft_z / vps_deposit_fft_z[_slab]) of this
+ *                         rank's slab, nx = N / world: per kz chunk the y passes into the send buffers, ONE grouped
+ *                         ncclSend / ncclRecv exchange per chunk on the communication stream, the binning x pass of the
+ *                         received blocks (component |F|^2 summed before the shell search) -- all y passes are enqueued
+ *                         first, so chunk c travels while c + 1 is transformed and is binned while c + 1 travels.  Needs the
+ *                         tables of vps_set_binning; blocks carry only the rows a shell can reach.  Accumulates into
+ *                         psum_dev / (count != 0) nsample_dev; xwork_dev: vps_spectrum_zimages_workspace_bytes.
+ *   vps_allreduce_shells  sum of the accumulators over the ranks (ncclAllReduce, float64 + uint64), on the context's stream */
+int vps_comm_unique_id(char* id128);
+int vps_comm_create(vps_ctx* ctx, int rank, int world, const char* id128);
+int vps_comm_destroy(vps_ctx* ctx);
+int vps_comm_info(vps_ctx* ctx, int* rank, int* world);
+size_t vps_spectrum_zimages_workspace_bytes(int N, int nx, int G, int nchunks, int ncomp);
+int vps_spectrum_zimages(vps_ctx* ctx, int N, int nx, const void* const* zimg_devs, int ncomp, int nchunks, void* xwork_dev,
+                         int count, double* psum_dev, unsigned long long* nsample_dev);
+int vps_allreduce_shells(vps_ctx* ctx, double* psum_dev, unsigned long long* nsample_dev, int nbins);
+
 /* Single-GPU convenience: full |F(k)|^2 binning of one real field.
  * field_dev [N][N][N] float32 is preserved; work_dev: vps_power_workspace_bytes(N). */
 size_t vps_power_workspace_bytes(int N);

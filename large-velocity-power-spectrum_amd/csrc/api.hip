@@ -117,6 +117,7 @@ int vps_destroy(vps_ctx* ctx) {
   if (!ctx) return VPS_OK;
   vps_device_guard guard(ctx);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm) (void)vps_comm_destroy(ctx);
   vps_fft_free_tables(ctx);
   if (ctx->d_k2) (void)hipFree(ctx->d_k2);
   if (ctx->d_thr) (void)hipFree(ctx->d_thr);

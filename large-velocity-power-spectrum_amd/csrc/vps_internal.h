@@ -20,6 +20,8 @@ struct vps_fft_tables {
   float2* tw_r2c = nullptr;    // exp(-2 pi i k / (2 NC)), k < NC  (real length 2 NC)
 };
 
+struct vps_comm;   // comm.hip: RCCL communicator, communication stream, events
+
 struct vps_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -63,6 +65,8 @@ struct vps_ctx {
   // small device scratch for the NN lattice axes
   double* d_axes = nullptr;
   size_t axes_cap = 0;
+
+  vps_comm* comm = nullptr;      // vps_comm_create
 
   unsigned nn_open_points = 0;   // diagnostics: lattice points the last NN scatter pass left to the exact fallback
 

@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.environ.get("VPS_LIB_PATH") or os.path.join(_HERE, "libvps_hip.so")  # override: experiments only
-SOURCES = ("api.hip", "deposit.hip", "nn.hip", "fft.hip", "hist.hip", "preprocess.hip")
+SOURCES = ("api.hip", "deposit.hip", "nn.hip", "fft.hip", "hist.hip", "preprocess.hip", "comm.hip")
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics")
 
 # every symbol include/vps_hip.h declares: (name, restype, argtypes)
@@ -87,6 +87,13 @@ SYMBOLS = (
                                _vp, _vp)),
     ("vps_fft_x_bin_chunk", C.c_int, (_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp),
                                      C.c_int, C.c_int, _vp, _vp)),
+    ("vps_comm_unique_id", C.c_int, (C.c_char_p,)),
+    ("vps_comm_create", C.c_int, (_vp, C.c_int, C.c_int, C.c_char_p)),
+    ("vps_comm_destroy", C.c_int, (_vp,)),
+    ("vps_comm_info", C.c_int, (_vp, C.POINTER(C.c_int), C.POINTER(C.c_int))),
+    ("vps_spectrum_zimages_workspace_bytes", C.c_size_t, (C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)),
+    ("vps_spectrum_zimages", C.c_int, (_vp, C.c_int, C.c_int, C.POINTER(_vp), C.c_int, C.c_int, _vp, C.c_int, _vp, _vp)),
+    ("vps_allreduce_shells", C.c_int, (_vp, _vp, _vp, C.c_int)),
     ("vps_power_workspace_bytes", C.c_size_t, (C.c_int,)),
     ("vps_power_bin", C.c_int, (_vp, C.c_int, _vp, _vp, _vp, _vp)),
     ("vps_rfft3", C.c_int, (_vp, C.c_int, _vp, _vp, _vp)),
@@ -151,7 +158,7 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise VpsError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise VpsError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode(errors="replace")))

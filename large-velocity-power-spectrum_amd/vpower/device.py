@@ -540,6 +540,40 @@ class HipKernels:
                                                int(bool(packed)), ptrs, len(comps), 1 if count else 0,
                                                self._ptr(psum, torch.float64), self._ptr(nsample, torch.int64)))
 
+    # -- the slab exchange inside the library (RCCL behind the C ABI) -------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId: made on one rank, handed to all (the host moves them)."""
+        buf = C.create_string_buffer(128)
+        lib = _ffi.lib()
+        rc = lib.vps_comm_unique_id(buf)
+        if rc != 0:
+            raise _ffi.VpsError("vps_comm_unique_id failed (%d): %s" % (rc, lib.vps_last_error(None).decode()))
+        return buf.raw
+
+    def comm_create(self, rank, world, uid):
+        """Collective over the job's ranks: an RCCL communicator on this context's device."""
+        self._chk(self.lib.vps_comm_create(self.ctx, int(rank), int(world), bytes(uid)))
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def comm_destroy(self):
+        self._chk(self.lib.vps_comm_destroy(self.ctx))
+
+    def spectrum_zimages(self, zimgs, N, nx, nchunks, psum, nsample, count=True):
+        """vps_spectrum_zimages: chunked y pass -> grouped ncclSend / ncclRecv -> binning x pass of up to three z images,
+        all inside the library (its own communication stream and events)."""
+        self._stream()
+        G = self.comm_world
+        ptrs = (C.c_void_p * len(zimgs))(*[self._ptr(z, torch.complex64).value for z in zimgs])
+        work = self.workspace("exchange", self.lib.vps_spectrum_zimages_workspace_bytes(int(N), int(nx), G, int(nchunks), len(zimgs)))
+        self._chk(self.lib.vps_spectrum_zimages(self.ctx, int(N), int(nx), ptrs, len(zimgs), int(nchunks), self._ptr(work),
+                                                1 if count else 0, self._ptr(psum, torch.float64), self._ptr(nsample, torch.int64)))
+
+    def allreduce_shells(self, psum, nsample):
+        self._stream()
+        self._chk(self.lib.vps_allreduce_shells(self.ctx, self._ptr(psum, torch.float64), self._ptr(nsample, torch.int64),
+                                                int(psum.numel())))
+
     def fft_x_write(self, lines, N, nlines, nseg, seg_stride, out):
         self._stream()
         self._chk(self.lib.vps_fft_x(self.ctx, N, nlines, 0, 0, self._ptr(lines, torch.complex64), nseg,
@@ -671,6 +705,35 @@ class SlabComm:
             return t
         self.dist.all_reduce(t, group=self.group)
         return t
+
+
+class LibraryComm(SlabComm):
+    """The same two collectives, run INSIDE libvps_hip.so over RCCL (vps_comm_create / vps_spectrum_zimages /
+    vps_allreduce_shells): what a host without torch.distributed uses.  `PowerPipeline` hands whole groups of z images to
+    the library, which owns the chunk pipeline (communication stream, events).  rank / world / uid come from the host --
+    here: from an initialised torch.distributed group (only to move the 128-byte id), or explicitly."""
+
+    def __init__(self, kernels, rank=None, world=None, uid=None, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        if rank is None:
+            if not (dist.is_available() and dist.is_initialized()):
+                rank, world = 0, 1
+            else:
+                rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if uid is None:
+            box = [HipKernels.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            uid = box[0]
+        self.rank, self.world = int(rank), int(world)
+        self.enabled, self.force, self.backend = True, True, "library"
+        self.k = kernels
+        kernels.comm_create(self.rank, self.world, uid)
+
+    def all_reduce_shells(self, psum, nsample):
+        self.k.allreduce_shells(psum, nsample)
 
 
 class PowerPipeline:
@@ -810,6 +873,13 @@ class PowerPipeline:
         """x-side of the transform for z images (HipKernels.fft_z / deposit_fft_z): per kz chunk, y pass into the
         send buffer, all-to-all started at once, then -- as chunks arrive -- x pass + shell sums."""
         group = 1 if os.environ.get("VPS_X_PER_COMPONENT") == "1" else 3
+        if isinstance(self.comm, LibraryComm):     # the whole chunk pipeline runs inside the library (RCCL)
+            self.prepare()
+            if psum is None:
+                psum, nsample = self.new_accumulators()
+            for i in range(0, len(zimgs), group):
+                self.k.spectrum_zimages(zimgs[i:i + group], self.N, self.nx, self.nchunks, psum, nsample, count=count and i == 0)
+            return psum, nsample
         for i in range(0, len(zimgs), group):      # one group in flight at a time (send + receive buffers of 3 fields)
             psum, nsample = self.finish_zimages(self.start_zimages(zimgs[i:i + group]), psum, nsample,
                                                 count=count and i == 0)
@@ -892,8 +962,11 @@ class PowerPipeline:
         """Reduce over ranks and build the reference's (nbins,4) table
         [centre, P, Psum, Nsample] (interp.py:1478-1480 / parallel_optimized.py:185-188),
         before the 4 pi k^2 factor."""
-        self.comm.all_reduce_sum(psum)
-        self.comm.all_reduce_sum(nsample)
+        if isinstance(self.comm, LibraryComm):
+            self.comm.all_reduce_shells(psum, nsample)
+        else:
+            self.comm.all_reduce_sum(psum)
+            self.comm.all_reduce_sum(nsample)
         buf = getattr(self, "_acc_buf", None)
         if (buf is not None and psum.data_ptr() == buf.data_ptr()
                 and nsample.data_ptr() == buf.data_ptr() + 8 * self.nbins):

@@ -109,7 +109,50 @@ def test_rccl_collectives_single_rank(tmp_path):
         assert np.allclose(tab[:, 2], ref[:, 2], rtol=2e-5, atol=0)
 
 
-def _nccl_worker(rank, world, port, N, Np, out_dir):
+def _library_rccl_worker(rank, port, N, Np, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "large-velocity-power-spectrum_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["VPS_A2A_CHUNKS"] = "4"
+    torch.cuda.set_device(0)
+    from vpower import device, synth
+    K = device.default_kernels(0)
+    pos, vel, mass, dens = synth.particles(37, Np, 1.0)
+    comm = device.LibraryComm(K, rank=0, world=1, uid=device.HipKernels.comm_unique_id())      # no torch.distributed at all
+    pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=comm)
+    assert pipe.chunked and pipe.nchunks == 4 and comm.backend == "library"
+    d = [K.to_device(a) for a in (pos, vel, dens)]
+    tabs = []
+    for q in (device.VELOCITY, device.ENERGY):
+        z = K.deposit_fft_z(d[0], d[1], d[2], N, 1.0, 0, N, q)
+        tabs.append(pipe.finish(*pipe.accumulate_zimages([z[i] for i in range(z.shape[0])])))
+        tabs.append(pipe.finish(*pipe.accumulate_zimages([z[i] for i in range(z.shape[0])])))    # buffers and events re-used
+    np.save(os.path.join(out_dir, "tab_lib.npy"), np.stack(tabs))
+    K.comm_destroy()
+
+
+def test_library_rccl_exchange_single_rank(tmp_path):
+    """The exchange behind the C ABI (vps_comm_create / vps_spectrum_zimages / vps_allreduce_shells: RCCL loaded by the
+    library, grouped ncclSend / ncclRecv per kz chunk on its own stream, events against the context's stream, ncclAllReduce of
+    the float64 / uint64 accumulators) on the one GPU of the test box: a one-rank communicator made from a unique id, no
+    torch.distributed involved.  Velocity (three components per launch) and energy against the oracle, twice each."""
+    import torch.multiprocessing as mp
+    from vpower import synth
+    N, Np = 128, 200000
+    mp.spawn(_library_rccl_worker, args=(_free_port(), N, Np, str(tmp_path)), nprocs=1, join=True)
+    pos, vel, mass, dens = synth.particles(37, Np, 1.0)
+    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
+    v, m = orc.vm_from_vec_grid(orc.deposit_to_grid_fast(vec, pos, N, 1.0), 1.0 / N, zero_empty=True)
+    tabs = np.load(tmp_path / "tab_lib.npy")
+    for i, q in enumerate(("velocity", "velocity", "energy", "energy")):
+        ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, 1.0 / N, q)
+        ref[:, 1] /= np.where(ref[:, 0] > 0, 4 * np.pi * ref[:, 0] ** 2, 1)
+        assert np.array_equal(tabs[i][:, 3], ref[:, 3])
+        assert np.allclose(tabs[i][:, 2], ref[:, 2], rtol=2e-5, atol=0)
+
+
+def _nccl_worker(rank, world, port, N, Np, out_dir, transport="torch"):
     for p in (ROOT, os.path.join(ROOT, "large-velocity-power-spectrum_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -124,8 +167,9 @@ def _nccl_worker(rank, world, port, N, Np, out_dir):
         from vpower import device, synth
         K = device.default_kernels(rank)
         pos, vel, mass, dens = synth.particles(35, Np, 1.0)
-        pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=device.SlabComm())
-        assert pipe.comm.backend == "nccl" and pipe.comm.world == world and pipe.chunked
+        comm = device.SlabComm() if transport == "torch" else device.LibraryComm(K)    # the latter: RCCL inside libvps_hip.so
+        pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=comm)
+        assert pipe.comm.backend == ("nccl" if transport == "torch" else "library") and pipe.comm.world == world and pipe.chunked
         d = [K.to_device(a) for a in (pos, vel, dens)]
         z = K.deposit_fft_z(d[0], d[1], d[2], N, 1.0, pipe.x0, pipe.nx, device.VELOCITY)
         tab = pipe.finish(*pipe.accumulate_zimages([z[0], z[1], z[2]]))
@@ -134,15 +178,16 @@ def _nccl_worker(rank, world, port, N, Np, out_dir):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport", ["torch", "library"])
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL cannot put two ranks on one device)")
-def test_two_ranks_two_gpus_rccl(tmp_path):
+def test_two_ranks_two_gpus_rccl(tmp_path, transport):
     """The slab path over RCCL between two real devices (runs wherever two GPUs are visible; the 1-GPU test box
     skips it): chunked all-to-all of the fused z images, x pass on the received blocks, all-reduce; every rank's
     table against the oracle."""
     import torch.multiprocessing as mp
     from vpower import synth
     N, Np, world = 128, 300000, 2
-    mp.spawn(_nccl_worker, args=(world, _free_port(), N, Np, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_nccl_worker, args=(world, _free_port(), N, Np, str(tmp_path), transport), nprocs=world, join=True)
     pos, vel, mass, dens = synth.particles(35, Np, 1.0)
     vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
     v, m = orc.vm_from_vec_grid(orc.deposit_to_grid_fast(vec, pos, N, 1.0), 1.0 / N, zero_empty=True)
