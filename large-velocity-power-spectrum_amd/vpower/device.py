@@ -173,10 +173,15 @@ class HipKernels:
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
+    h2d_copies = 0      # host -> device uploads made through to_device (tests assert residency with it)
+    h2d_bytes = 0
+
     def to_device(self, arr, dtype=None):
         t = torch.as_tensor(np.ascontiguousarray(arr))
         if dtype is not None:
             t = t.to(dtype)
+        self.h2d_copies += 1
+        self.h2d_bytes += t.numel() * t.element_size()
         return t.to(self.device)
 
     def workspace(self, key, nbytes):

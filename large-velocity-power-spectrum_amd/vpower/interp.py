@@ -79,10 +79,28 @@ def load_snapshot(file, Lbox=1.0, remove_bulk_velocity=True, shift_to_origin=Tru
     return gp
 
 
+def _fingerprint(a):
+    """Cheap identity of a host array's CONTENT: where it lives, its layout, and a strided sample of its values -- enough
+    to notice an in-place edit of the whole array (shift, rescale) between two device calls."""
+    a = np.asarray(a)
+    flat = a.reshape(-1)
+    step = max(1, flat.size // 257)
+    return (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str, flat[::step][:257].tobytes())
+
+
 class GasParticles:
-    """interp.py:135-450 (I/O-free part)."""
+    """interp.py:135-450 (I/O-free part).
+
+    The particle arrays are numpy arrays, as in the reference; their device copies (positions as given, float32
+    velocities and densities, the [rho v, rho] payload) are made on first use and KEPT: a second `ann_interp_to_field` /
+    `deposit_to_field(N).spctrm(q)` on the same object uploads nothing.  A copy is dropped when its attribute is assigned
+    again or when the array's content fingerprint changed (an in-place edit); `invalidate_device()` drops them all."""
+
+    _DEVICE_ATTRS = {"pos": ("pos",), "mass": ("mass",), "density": ("rho", "payload"), "velocity": ("vel", "payload"),
+                     "v": ("vel", "payload")}
 
     def __init__(self, pos, mass, density, velocity, Lbox) -> None:
+        object.__setattr__(self, "_devcache", {})
         self.pos = pos
         self.mass = mass
         self.density = density
@@ -91,17 +109,71 @@ class GasParticles:
         self.r = self.h()
         self.v = self.velocity
 
+    def __setattr__(self, name, value):
+        for key in self._DEVICE_ATTRS.get(name, ()):
+            self._devcache.pop(key, None)
+        object.__setattr__(self, name, value)
+
+    def invalidate_device(self):
+        self._devcache.clear()
+
+    def _cached(self, key, sources, make):
+        """Device tensor `key`, rebuilt by make() when one of the host arrays it was made from changed."""
+        fp = tuple(_fingerprint(a) for a in sources)
+        hit = self._devcache.get(key)
+        if hit is not None and hit[0] == fp:
+            return hit[1]
+        t = make()
+        self._devcache[key] = (fp, t)
+        return t
+
+    def _device_pos(self, k):
+        return self._cached("pos", (self.pos,), lambda: _pos_tensor(k, self.pos))
+
+    def _device_vel(self, k):
+        return self._cached("vel", (self.v,), lambda: k.to_device(np.asarray(self.v), torch.float32))
+
+    def _device_rho(self, k):
+        return self._cached("rho", (self.density,), lambda: k.to_device(np.asarray(self.density), torch.float32))
+
+    def _device_mass(self, k):
+        return self._cached("mass", (self.mass,), lambda: k.to_device(np.asarray(self.mass), torch.float32))
+
     def __len__(self) -> int:
         return len(self.pos)
 
     def __getitem__(self, index):
         return GasParticles(self.pos[index], self.mass[index], self.density[index], self.v[index], self.Lbox)
 
+    def _preprocess_on_device(self, shift, bulk):
+        """vps_preprocess on the resident copies (two device reductions + one elementwise pass, interp.py:169-182), the host
+        arrays then updated from them -- when those are float32 (positions may be float64), so that nothing is rounded that
+        the reference would not round.  Returns False when the host arrays have to take numpy's route."""
+        pos, v = np.asarray(self.pos), np.asarray(self.v)
+        if not torch.cuda.is_available() or pos.dtype not in (np.float32, np.float64) or v.dtype != np.float32 \
+                or not pos.flags.writeable or not v.flags.writeable:
+            return False
+        k = _kernels()
+        dpos, dvel = self._device_pos(k), self._device_vel(k)
+        k.preprocess(dpos, dvel if bulk else None, self._device_mass(k) if bulk else None, shift, bulk)
+        if shift:
+            pos[...] = dpos.cpu().numpy()
+            self._devcache["pos"] = ((_fingerprint(self.pos),), dpos)
+        if bulk:
+            v[...] = dvel.cpu().numpy()
+            self._devcache["vel"] = ((_fingerprint(self.v),), dvel)
+            self._devcache.pop("payload", None)
+        return True
+
     def shift_to_origin(self) -> None:
+        if self._preprocess_on_device(True, False):
+            return
         for a in range(3):
             self.pos[:, a] -= np.min(self.pos[:, a])
 
     def remove_bulk_velocity(self) -> None:
+        if self._preprocess_on_device(False, True):
+            return
         M = np.sum(self.mass)
         for a in range(3):
             self.v[:, a] -= np.sum(self.mass * self.v[:, a]) / M
@@ -119,9 +191,8 @@ class GasParticles:
                          self.v[:, 2] * self.density, self.density), axis=1)
 
     def _device_payload(self, k):
-        vel = k.to_device(np.asarray(self.v), torch.float32)
-        rho = k.to_device(np.asarray(self.density), torch.float32)
-        return k.density_velocity_vector(vel, rho)
+        return self._cached("payload", (self.v, self.density),
+                            lambda: k.density_velocity_vector(self._device_vel(k), self._device_rho(k)))
 
     def ann_interp_to_field(self, Nsize, eps=0.0, treetype="kd", searchtype="standard"):
         """Exact-NN resampling onto the library lattice, then v=rho v/rho, m=rho*Lcell^3
@@ -132,7 +203,7 @@ class GasParticles:
         k = _kernels()
         Lcell = self.Lbox / Nsize
         ax = _lattice_axis(self.Lbox, Nsize)
-        grid, _ = k.nn_resample_field(_pos_tensor(k, self.pos), self._device_payload(k), (ax, ax, ax), 0, Nsize, Lcell)
+        grid, _ = k.nn_resample_field(self._device_pos(k), self._device_payload(k), (ax, ax, ax), 0, Nsize, Lcell)
         return BoxField._from_device(grid, Lcell)
 
     def deposit_to_field(self, Nsize, assignment="ngp"):
@@ -143,13 +214,11 @@ class GasParticles:
         [rho v, rho] over 8 / 27 cells; `BoxField.spctrm(..., deconvolve=True)` then divides the
         spectrum by the assignment window."""
         k = _kernels()
-        vel = k.to_device(np.asarray(self.v), torch.float32)
-        rho = k.to_device(np.asarray(self.density), torch.float32)
+        vel, rho = self._device_vel(k), self._device_rho(k)
         if assignment != "ngp":
             if assignment not in _dev.ASSIGNMENT_ORDER:
                 raise Exception("assignment must be 'ngp', 'cic' or 'tsc'")
-            pos_e, pay_e = k.assign_expand(_pos_tensor(k, self.pos), k.density_velocity_vector(vel, rho), Nsize, self.Lbox,
-                                           assignment)
+            pos_e, pay_e = k.assign_expand(self._device_pos(k), self._device_payload(k), Nsize, self.Lbox, assignment)
             grid = k.deposit(pos_e, pay_e, Nsize, self.Lbox, 0, Nsize)
             k.field_algebra(grid, _dev.VM, 0, self.Lbox / Nsize)
             box = BoxField._from_device(grid, self.Lbox / Nsize)
@@ -157,7 +226,7 @@ class GasParticles:
             return box
         # The grid itself is built on first use: `deposit_to_field(N).spctrm(...)`, the usual composition, goes
         # from the particles to P(k) through the fused deposit + z-pass kernel and never writes a grid.
-        return BoxField._from_particles((_pos_tensor(k, self.pos), vel, rho), Nsize, self.Lbox)
+        return BoxField._from_particles((self._device_pos(k), vel, rho), Nsize, self.Lbox)
 
     def total_mass(self) -> float:
         return np.sum(self.mass)

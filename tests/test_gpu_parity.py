@@ -746,3 +746,44 @@ def test_config2_properties(K):
     assert np.array_equal(t_step[:, 3], ref2[:, 3]) and np.array_equal(t_step[:, 3], tab[:, 3])
     assert np.allclose(t_step[:, 2], ref2[:, 2], rtol=PSUM_RTOL, atol=0)
     assert np.allclose(t_step[:, 1], ref2[:, 1], rtol=PSUM_RTOL, atol=0)
+
+
+# ------------------------------------------------ particle data stays resident across library calls ----
+def test_particles_stay_resident_across_library_calls(K):
+    """interp.py:84-131, 169-182, 246-277 on the device: the particle arrays are uploaded once per GasParticles object;
+    shift_to_origin / remove_bulk_velocity run vps_preprocess on the resident copies (and update the host arrays); a second
+    deposit_to_field(N).spctrm(q) or ann_interp_to_field on the same object performs no host-to-device copy; assigning an
+    attribute or editing an array in place drops exactly the copies that depend on it."""
+    from vpower import interp
+    rng = np.random.default_rng(3)
+    Np, N, L = 200_000, 64, 2.0
+    pos = (0.3 + rng.random((Np, 3)) * (L - 0.3)).astype(np.float32)
+    vel = (rng.standard_normal((Np, 3)) + np.array([0.5, -1.0, 0.2])).astype(np.float32)
+    dens = np.exp(0.5 * rng.standard_normal(Np)).astype(np.float32)
+    mass = np.ones(Np, dtype=np.float32)
+    ref_pos, ref_vel = orc.preprocess_script(pos, mass, vel)
+    gp = interp.GasParticles(pos.copy(), mass, dens, vel.copy(), L)
+    gp.remove_bulk_velocity()
+    gp.shift_to_origin()
+    assert np.array_equal(gp.pos, ref_pos)                               # float32 positions: the same subtraction
+    assert np.allclose(gp.v, ref_vel, rtol=0, atol=2e-6)                 # bulk velocity summed in float64 on the device
+    n0 = K.h2d_copies
+    sp1 = gp.deposit_to_field(N).spctrm("velocity")
+    n1 = K.h2d_copies
+    assert n1 - n0 == 1                                                  # the densities (positions and velocities were already there)
+    sp2 = gp.deposit_to_field(N).spctrm("momentum")
+    box = gp.ann_interp_to_field(N)
+    sp3 = box.spctrm("energy")
+    assert K.h2d_copies == n1                                            # nothing uploaded: positions, velocities, densities resident
+    assert np.isfinite(sp2.Psum).all() and np.isfinite(sp3.Psum).all()
+    # same numbers as a fresh object built from the preprocessed host arrays
+    sp1b = interp.GasParticles(gp.pos.copy(), mass, dens, gp.v.copy(), L).deposit_to_field(N).spctrm("velocity")
+    assert np.array_equal(sp1.Nsample, sp1b.Nsample) and np.allclose(sp1.Psum, sp1b.Psum, rtol=1e-6)
+    # an in-place edit is noticed (fingerprint), an assignment drops the copy
+    n2 = K.h2d_copies
+    gp.v[:, 0] *= 2.0
+    sp4 = gp.deposit_to_field(N).spctrm("velocity")
+    assert K.h2d_copies == n2 + 1 and not np.allclose(sp4.Psum, sp1.Psum, rtol=1e-3)
+    gp.density = dens * 2
+    gp.deposit_to_field(N).spctrm("momentum")
+    assert K.h2d_copies == n2 + 2
