@@ -58,6 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short C2 / C3 runs of the default line")
+    ap.add_argument("--no-full-check", action="store_true",
+                    help="skip the full-size checks of the timed step's tables (exact shell counts, Parseval over all modes)")
     ap.add_argument("--unfused", action="store_true", help="NGP route: separate deposit and z-pass kernels (grid through HBM)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the roofline")
     ap.add_argument("--emulate-ranks", type=int, default=0,
@@ -317,10 +319,14 @@ def compare_tables(dev_tabs, ora_tabs):
     return eq, worst
 
 
-def sample_size(route, N, Np):
-    """Grid of the oracle-checked / CPU-timed sample: same particle density, at most 256^3 (NGP) or
-    128^3 (the NN routes: the oracle's kd-tree search is the slow part)."""
-    Ns = min(N, 256 if route == "ngp" else 128)
+def sample_size(route, N, Np, cpu=False):
+    """Grid of the oracle-checked sample: same particle density, at most 256^3 (NGP) or 128^3 (the NN routes: the
+    oracle's kd-tree search is the slow part).  cpu: the sample the CPU baseline is timed on -- the size of BASELINE config 2,
+    512^3 (configs 3-5 are extrapolated from there), 256^3 for the NN routes."""
+    if cpu:
+        Ns = min(N, 512 if route == "ngp" else 256 if route == "nn" else 128)
+    else:
+        Ns = min(N, 256 if route == "ngp" else 128)
     Nps = max(1000, int(round(Np * (Ns / N) ** 3)))
     return Ns, Nps
 
@@ -416,7 +422,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     # (one plane against hundreds): the main ones are those within a factor 8 of the longest
     def main_of(v):
         return v[v * 8.0 >= v.max()] if len(v) else v
-    main = {"fft_y": main_of(per["fft_y"]), "fft_x": main_of(per["fft_x"]), "fft_z": per["fft_z"], "nn_query": per["nn_query"]}
+    main = {"fft_y": main_of(per["fft_y"]), "fft_x": main_of(per["fft_x"]), "fft_z": per["fft_z"], "nn_query": main_of(per["nn_query"])}
     Nps = Np / G      # particles inside one rank's slab (uniform positions)
     # algorithmic HBM bytes of the main launches of ONE step, per kernel family (DESIGN.md "Kernels"): what the kernels
     # have to move -- rows (ky, kz) beyond the last shell edge are neither written by the y pass nor read by the x pass
@@ -474,19 +480,80 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
                      "launches_per_step": launches_per_step[dom]},
         "per_kernel_frac_of_hbm_peak": {k: step_bytes[k] / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS for k in kms},
         "kept_row_fraction": keep,
+        "launch_ms": {k: [round(float(x), 3) for x in v[:12]] for k, v in per.items() if len(v) and k in ("nn_query", "nn_build")},
     }
     if exchange_rows is not None:
         res["exchange_row_fraction"] = exchange_rows   # rows per kz plane in the exchanged blocks / N
     finite = all(np.isfinite(t[:, 2]).all() and t[:, 3].sum() > 0 for t in tabs.values())
     if rank == 0 and not os.environ.get("VPS_BENCH_NOCHECK"):      # (timing-only kernel variants produce garbage)
         assert finite, "non-finite shell sums"
+    # ---- the tables of the TIMED, full-size step itself: exact shell counts; Parseval over all modes (NGP routes) ----
+    # (the oracle cannot follow at this size; these are the size-independent properties of SURVEY.md section 4, computed with
+    # torch float64 as the calculator: oracle/gpu_checks.py.  What they exercise are the kernels that dominate the timed
+    # region -- wide y pass, 512-thread pencils, 64-bit sort keys, row-cut packing -- which the small oracle sample cannot.)
+    if not args.no_full_check and G == world and not os.environ.get("VPS_BENCH_NOCHECK"):
+        from oracle import gpu_checks as chk
+        counts = chk.shell_counts_exact(K.device, N, wl.pipe.k2, wl.pipe.thr)
+        full = {"nsample_exact": bool(all(np.array_equal(t[:, 3], counts) for t in tabs.values())),
+                "what": "timed step's tables: Nsample per shell vs the exact lattice count"}
+        if route == "ngp" and world == 1:
+            kmin_, kmax_, kres_ = chk.all_mode_k_range(N, L)
+            pall = device.PowerPipeline(N, L, kernels=K, comm=comm, flavour="script", kmin=kmin_, kmax=kmax_, kres=kres_)
+            keep_pipe, keep_acc = wl.pipe, (wl.psum, wl.nsample, wl.acc_buf)
+            wl.pipe = pall                                      # the same step(), its shells widened to the corners of the k cube
+            wl.psum, wl.nsample = pall.new_accumulators()
+            wl.acc_buf = pall._acc_buf
+            tall = wl.step()
+            wl.pipe, (wl.psum, wl.nsample, wl.acc_buf) = keep_pipe, keep_acc
+            want = chk.parseval_targets(chk.ngp_moments_float64(dpos, dvel, drho, N, L, quantities), N)
+            worst = 0.0
+            for q in quantities:
+                t_ = tall[q]
+                got = float(np.sum(t_[:, 2])) * (2 * np.pi / L) ** 3
+                worst = max(worst, abs(got - want[q]) / want[q])
+            full["parseval_max_rel"] = worst
+            full["what"] += "; sum over ALL modes of Psum (2 pi/L)^3 vs 0.5 (<f^2> - <f>^2) of the float64 NGP fields, every quantity"
+            del pall, tall
+        res["full_size_check"] = full
+        if rank == 0:
+            assert full["nsample_exact"], "shell counts of the timed step differ from the exact lattice counts"
+            assert full.get("parseval_max_rel", 0.0) <= PSUM_RTOL, "Parseval of the timed step: %.3g" % full["parseval_max_rel"]
+    # ---- gridding alone (BASELINE's "particles gridded/s"): the standalone NGP deposit -- bucket sort, LDS accumulation of
+    # [rho v, rho], field algebra, the three velocity fields written to HBM -- timed by itself.  (In the fused path the
+    # accumulation lives inside the z-pass launch and cannot be timed apart; the sort alone would flatter.)
+    gridding = None
+    del wl, tabs
+    K._work.clear()
+    torch.cuda.empty_cache()
+    if route == "ngp" and G == world and world == 1:
+        try:
+            g_ = K.deposit_field(dpos, dvel, drho, N, L, 0, N, device.VELOCITY)
+            K.timing(True)
+            for _ in range(2):
+                K.deposit_field(dpos, dvel, drho, N, L, 0, N, device.VELOCITY, out=g_)
+            tg = K.timing_get()
+            K.timing(False)
+            del g_
+            sort_ms, acc_ms = tg["deposit"][1] / 2, tg["algebra"][1] / 2
+            gridding = {"standalone_deposit_ms": sort_ms + acc_ms, "sort_ms": sort_ms, "accumulate_and_write_ms": acc_ms,
+                        "particles_per_s": Np / ((sort_ms + acc_ms) * 1e-3),
+                        "algorithmic_GBs": (28.0 * Np + 12.0 * float(N) ** 3) / ((sort_ms + acc_ms) * 1e-3) / 1e9,
+                        "what": "vps_deposit_field(velocity): sort + LDS accumulation + algebra + 3 float32 fields of N^3 to HBM"}
+            res["gridding"] = gridding
+            res["particles_per_s_sort_only"] = res["particles_per_s"]
+            res["particles_per_s"] = gridding["particles_per_s"]
+            res["gridding_note"] = ("standalone NGP deposit (sort + accumulation + fields written); the fused step does the "
+                                    "accumulation inside the z-pass launch: see gridding, particles_per_s_sort_only")
+        except Exception as e:      # (out of memory on a box with less HBM: keep the sort-only figure, say so)
+            res["gridding_note"] += "; standalone deposit not timed: %s" % str(e)[:80]
+            K.timing(False)
     # release the big buffers before the sample / the next config
-    del wl, dpos, dvel, drho, tabs
+    del dpos, dvel, drho
     K._work.clear()
     torch.cuda.empty_cache()
 
-    # ---- the same step function on a small sample, against the oracle; CPU baseline on that sample ----
-    if (want_parity or want_cpu) and G == world:
+    # ---- the same step function on a small sample, against the oracle ----
+    if want_parity and G == world:
         Ns, Nps_ = sample_size(route, N, Np)
         while Ns % (2 * world):
             Ns *= 2
@@ -496,44 +563,62 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
         dev_tabs = swl.step()
         del swl
         if rank == 0:
-            ora_tabs, t1 = oracle_tables(route, quantities, flavour, Ns, L, pos, vel, dens)
-            if want_parity:
-                eq, worst = compare_tables(dev_tabs, ora_tabs)
-                res["parity"] = {"sample": "%d^3 grid, %d particles (the config's particle density), same step() as the timed region, "
-                                           "vs oracle/vps_oracle.py" % (Ns, Nps_),
-                                 "nsample_equal": eq, "psum_max_rel": worst, "psum_rtol": PSUM_RTOL}
-                if not os.environ.get("VPS_BENCH_NOCHECK"):
-                    assert eq, "shell counts differ from the oracle"
-                    assert worst <= PSUM_RTOL, "shell sums differ from the oracle: %.3g" % worst
-            if want_cpu:
-                from oracle import vps_oracle as orc
-                scale = (float(N) / Ns) ** 3
-                unit = "grid cells*components/s"
-                res["cpu_baseline"] = {
-                    "value": Ns ** 3 * nfields / t1["total"], "unit": unit, "cores": 1, "kind": "port",
-                    "sample": "oracle/vps_oracle.py (numpy, float64, 1 thread -- the reference pins FFTW threads=1, interp.py:1382) on "
-                              "%d^3 cells, %d particles = 1/%d of the workload at equal particle density: %s"
-                              % (Ns, Nps_, round(scale), ", ".join("%s %.2fs" % kv for kv in t1.items())),
-                    "seconds": t1["total"],
-                    "extrapolated_seconds_full_size": t1["total"] * scale,
-                    "extrapolation": "by the algorithmic-bytes ratio (N/Ns)^3 (SURVEY.md 8d); not measured",
-                    "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
-                if route != "script":
-                    nthr = os.cpu_count() or 1
-                    orc.set_fft_workers(nthr)
-                    try:
-                        _, t2 = oracle_tables(route, quantities, flavour, Ns, L, pos, vel, dens)
-                    finally:
-                        orc.set_fft_workers(1)
-                    res["cpu_baseline_allcores"] = {
-                        "value": Ns ** 3 * nfields / t2["total"], "unit": unit, "cores": nthr, "kind": "port",
-                        "sample": "same sample; the 3-D transforms threaded over %d cores (scipy.fft workers), gridding and "
-                                  "histograms remain single-threaded numpy: %s"
-                                  % (nthr, ", ".join("%s %.2fs" % kv for kv in t2.items())),
-                        "seconds": t2["total"], "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
+            ora_tabs, _ = oracle_tables(route, quantities, flavour, Ns, L, pos, vel, dens)
+            eq, worst = compare_tables(dev_tabs, ora_tabs)
+            res["parity"] = {"sample": "%d^3 grid, %d particles (the config's particle density), same step() as the timed region, "
+                                       "vs oracle/vps_oracle.py" % (Ns, Nps_),
+                             "nsample_equal": eq, "psum_max_rel": worst, "psum_rtol": PSUM_RTOL}
+            if not os.environ.get("VPS_BENCH_NOCHECK"):
+                assert eq, "shell counts differ from the oracle"
+                assert worst <= PSUM_RTOL, "shell sums differ from the oracle: %.3g" % worst
         K._work.clear()
         torch.cuda.empty_cache()
     return res
+
+
+def cpu_baseline_legs(cfg):
+    """The CPU side of the measurement (rank 0, one GPU run only; AFTER every device timing: the threaded leg leaves worker
+    pools behind that slow the host's kernel launches).  One core: the oracle at the size of BASELINE config 2 (512^3 --
+    SURVEY.md 8d makes it the base from which configs 3-5 are extrapolated; 256^3 for the NN route), at the config's particle
+    density, stage by stage.  All cores: the same on the 256^3 / 128^3 parity sample with the transforms threaded."""
+    from vpower import synth
+    from oracle import vps_oracle as orc
+    N, Np, off = synth.CONFIGS[cfg]
+    route, quantities, flavour = synth.WORKLOADS[cfg]
+    L, lognormal = 1.0, cfg != "C1"
+    nfields = sum(NCOMP[q] for q in quantities)
+    out = {}
+    Nc, Npc = sample_size(route, N, Np, cpu=True)
+    pos, vel, _, dens = synth.particles(synth.BASE_SEED + 200 + off, Npc, L, lognormal)
+    _, t1 = oracle_tables(route, quantities, flavour, Nc, L, pos, vel, dens)
+    del pos, vel, dens
+    scale = (float(N) / Nc) ** 3
+    unit = "grid cells*components/s"
+    out["cpu_baseline"] = {
+        "value": Nc ** 3 * nfields / t1["total"], "unit": unit, "cores": 1, "kind": "port",
+        "sample": "oracle/vps_oracle.py (numpy, float64, 1 thread -- the reference pins FFTW threads=1, interp.py:1382) on "
+                  "%d^3 cells, %d particles = 1/%d of the workload at equal particle density: %s"
+                  % (Nc, Npc, round(scale), ", ".join("%s %.2fs" % kv for kv in t1.items())),
+        "seconds": t1["total"], "stage_seconds": dict(t1),
+        "extrapolated_seconds_full_size": t1["total"] * scale,
+        "extrapolation": "by the algorithmic-bytes ratio (N/%d)^3 (SURVEY.md 8d); not measured" % Nc,
+        "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
+    if route != "script":
+        Ns, Nps_ = sample_size(route, N, Np)
+        pos, vel, _, dens = synth.particles(synth.BASE_SEED + 100 + off, Nps_, L, lognormal)
+        nthr = os.cpu_count() or 1
+        orc.set_fft_workers(nthr)
+        try:
+            _, t2 = oracle_tables(route, quantities, flavour, Ns, L, pos, vel, dens)
+        finally:
+            orc.set_fft_workers(1)
+        out["cpu_baseline_allcores"] = {
+            "value": Ns ** 3 * nfields / t2["total"], "unit": unit, "cores": nthr, "kind": "port",
+            "sample": "the %d^3 parity sample (%d particles); the 3-D transforms threaded over %d cores (scipy.fft workers), "
+                      "gridding and histograms remain single-threaded numpy: %s"
+                      % (Ns, Nps_, nthr, ", ".join("%s %.2fs" % kv for kv in t2.items())),
+            "seconds": t2["total"], "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
+    return out
 
 
 def main(argv=None):
@@ -609,9 +694,12 @@ def main(argv=None):
             r = run_config(args, c, K, comm, world, rank, backend, steps=5, warmup=2, profile_steps=2,
                            want_parity=not args.no_parity, want_cpu=False)
             other[c] = {k: r[k] for k in ("ms_per_step", "value", "config", "particles_per_s", "fft_cells_per_s", "fft_stage",
-                                          "kernel_ms_per_step", "roofline", "per_kernel_frac_of_hbm_peak", "parity") if k in r}
+                                          "kernel_ms_per_step", "roofline", "per_kernel_frac_of_hbm_peak", "parity", "full_size_check", "gridding",
+                                          "particles_per_s_sort_only", "gridding_note", "launch_ms") if k in r}
             other[c]["steps"] = 5
         out["other_configs"] = other
+    if rank == 0 and single and not args.no_cpu_baseline:
+        out.update(cpu_baseline_legs(cfg))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1733,13 +1733,17 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
       sp.tile_r = tr;
     }
     {
-      vps_launch_timer tm(ctx, VPS_K_NN_QUERY);
+      // (each launch has its own event bracket: a bracket around both would also count the host's gap between them)
 #define VPS_NNS(CC)                                                                                            \
   do {                                                                                                         \
-    if (column)                                                                                                \
-      hipLaunchKernelGGL((nn_column_kernel<F, CC>), dim3((unsigned)tiles), dim3(NC_THREADS), 0, ctx->stream, pos, sp); \
-    else                                                                                                       \
-      hipLaunchKernelGGL((nn_scatter_kernel<F, CC>), dim3((unsigned)tiles), dim3(NT_THREADS), 0, ctx->stream, pos, sp); \
+    {                                                                                                          \
+      vps_launch_timer tm(ctx, VPS_K_NN_QUERY);                                                                \
+      if (column)                                                                                              \
+        hipLaunchKernelGGL((nn_column_kernel<F, CC>), dim3((unsigned)tiles), dim3(NC_THREADS), 0, ctx->stream, pos, sp); \
+      else                                                                                                     \
+        hipLaunchKernelGGL((nn_scatter_kernel<F, CC>), dim3((unsigned)tiles), dim3(NT_THREADS), 0, ctx->stream, pos, sp); \
+    }                                                                                                          \
+    vps_launch_timer tm2(ctx, VPS_K_NN_QUERY);                                                                 \
     hipLaunchKernelGGL((nn_fallback_kernel<F, CC>), dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, ctx->stream, \
                        pos, srec, start, g, err, dqx, dqy, dqz, x0, nx, nqy, nqz, sp.list, sp.list_count, payload, \
                        out, nn_idx, vol);                                                                      \

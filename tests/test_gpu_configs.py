@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 
 from helpers import golden, synth  # noqa: E402
 from oracle import vps_oracle as orc  # noqa: E402
+from oracle import gpu_checks as chk  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PSUM_RTOL = 2e-5   # Psum per non-empty bin vs the float64 oracle / reference
@@ -62,33 +63,17 @@ def _oracle_slab_fields(pos, vel, dens, N, L, x0, nx, quantity):
 
 
 def _shell_counts_exact(K, pipe):
-    """Number of modes of the full N^3 spectrum per bin, counted on the |k| octant with
-    multiplicities, with the device-independent rule thr[b] <= (k2x+k2y)+k2z < thr[b+1]
-    (float64, numpy's association; torch on the GPU is only the calculator here)."""
-    N = pipe.N
-    h = N // 2
-    k2 = torch.as_tensor(pipe.k2[: h + 1].copy(), dtype=torch.float64, device=K.device)
-    thr = torch.as_tensor(pipe.thr, dtype=torch.float64, device=K.device)
-    w = torch.full((h + 1,), 2, dtype=torch.int64, device=K.device)
-    w[0] = 1
-    w[h] = 1
-    counts = torch.zeros(pipe.nbins + 2, dtype=torch.int64, device=K.device)
-    wyz = (w[:, None] * w[None, :]).reshape(-1)
-    for i in range(h + 1):
-        s = ((k2[i] + k2[:, None]) + k2[None, :]).reshape(-1)
-        b = torch.bucketize(s, thr, right=True)            # 0: below thr[0]; nbins+1: >= thr[nbins]
-        counts.index_add_(0, b, wyz * int(w[i]))
-    return counts[1: pipe.nbins + 1].cpu().numpy()
+    """Exact number of modes per bin (oracle/gpu_checks.py: torch on the GPU is only the calculator)."""
+    return chk.shell_counts_exact(K.device, pipe.N, pipe.k2, pipe.thr)
 
 
 def _all_mode_pipeline(K, N, L):
     """A pipeline whose bins reach the box corners: every mode except k = 0 is binned, so that
     sum(Psum) obeys Parseval exactly."""
     from vpower import device
-    kmin = 2 * np.pi / L
-    kmax = (int(np.ceil(np.sqrt(3.0) * N / 2)) + 1) * kmin
+    kmin, kmax, kres = chk.all_mode_k_range(N, L)
     return device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False), flavour="script",
-                                kmin=kmin, kmax=kmax, kres=kmin)
+                                kmin=kmin, kmax=kmax, kres=kres)
 
 
 def _sum_and_sumsq(f, planes=32):
@@ -102,45 +87,8 @@ def _sum_and_sumsq(f, planes=32):
 
 
 def _ngp_moments_float64(K, dpos, dvel, drho, N, L, quantities, rows=128):
-    """Oracle-side statistics of the NGP fields at sizes no host array can follow: per quantity the float64 sum and sum
-    of squares of every component field, from a restatement of interp.py:1010-1013 + 272-273 + 523-525 + 546 in torch
-    float64 on the GPU (torch is only the calculator: python-style floor division for the cell index, index_add_ of
-    [rho v, rho] per x-slab of `rows` planes, v = rho v / rho with empty cells 0, m = rho Lcell^3).  No library call."""
-    Lcell = L / N
-    vol = Lcell ** 3
-    lc = torch.tensor(Lcell, dtype=dpos.dtype, device=dpos.device)
-    cx = (torch.floor_divide(dpos[:, 0], lc) % N).to(torch.int64)
-    out = {q: [[0.0, 0.0] for _ in range(1 if q == "energy" else 3)] for q in quantities}
-    for x0 in range(0, N, rows):
-        sel = torch.nonzero((cx >= x0) & (cx < x0 + rows)).squeeze(1)
-        p = dpos[sel]
-        flat = ((cx[sel] - x0) * N + (torch.floor_divide(p[:, 1], lc) % N).to(torch.int64)) * N \
-            + (torch.floor_divide(p[:, 2], lc) % N).to(torch.int64)
-        del p
-        d = drho[sel].double()
-        n3 = rows * N * N
-        rho = torch.zeros(n3, dtype=torch.float64, device=dpos.device).index_add_(0, flat, d)
-        inv = torch.where(rho > 0, 1.0 / rho, torch.zeros_like(rho))
-        v = []
-        for c in range(3):
-            a = torch.zeros(n3, dtype=torch.float64, device=dpos.device).index_add_(0, flat, d * dvel[sel, c].double())
-            v.append(a * inv)
-            del a
-        m = rho * vol
-        del rho, inv, flat, d, sel
-        for q in quantities:
-            if q == "velocity":
-                fs = v
-            elif q == "momentum":
-                fs = [v[c] * m for c in range(3)]
-            else:
-                fs = [m * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2])]
-            for c, f in enumerate(fs):
-                out[q][c][0] += float(f.sum().item())
-                out[q][c][1] += float((f * f).sum().item())
-            del fs
-        del v, m
-    return out
+    """Oracle-side float64 statistics of the NGP fields (oracle/gpu_checks.py); no library call."""
+    return chk.ngp_moments_float64(dpos, dvel, drho, N, L, quantities, rows)
 
 
 # ------------------------------------------- fused deposit + z/y passes, full-size lines ----
@@ -244,7 +192,7 @@ def test_config4_full_size_properties(K):
     dpos, dvel, drho = sy.particles_device(K, sy.BASE_SEED + off, Np, L)
     # Parseval targets from the oracle-side float64 restatement of the NGP fields (no HIP deposit involved)
     mom = _ngp_moments_float64(K, dpos, dvel, drho, N, L, ("velocity", "momentum", "energy"))
-    want = {q: sum(0.5 * (sq / N ** 3 - (s_ / N ** 3) ** 2) for s_, sq in mom[q]) for q in mom}
+    want = chk.parseval_targets(mom, N)
     _free(K)
     wl = bench.Workload(K, device.SlabComm(enabled=False), N, L, "ngp", ("velocity", "momentum", "energy"), "library",
                         dpos, dvel, drho)
