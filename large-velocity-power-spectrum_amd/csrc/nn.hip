@@ -1086,7 +1086,7 @@ __device__ __forceinline__ void nc_run_class(float (&b1)[NC_TZ], float (&b2)[NC_
       const unsigned me = k0 + 64u + (unsigned)lane;
       nxt = P[ord[me < end ? me : beg]];
     }
-    const int cnt = (int)min(64u, end - k0);
+    const int cnt = __builtin_amdgcn_readfirstlane((int)min(64u, end - k0));   // (scalar: the loop's exit test stays off the VALU)
     for (int i = 0; i < cnt; ++i) {
       const float px = nc_readlane(rec.x, i), py = nc_readlane(rec.y, i), pz = nc_readlane(rec.z, i);
       const int idx = __builtin_amdgcn_readlane(__float_as_int(rec.w), i);
@@ -1146,6 +1146,8 @@ __global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __res
 #endif
   constexpr int TD[3] = {NC_TX, NC_TY, NC_TZ};
   const int ntz = (p.nqz + NC_TZ - 1) / NC_TZ, nty = (p.nqy + NC_TY - 1) / NC_TY;
+  // (every XCD walking ONE contiguous range of tiles, so that its L2 serves the halo particles neighbouring tiles share:
+  // measured 16.5 against 16.2 ms -- not kept)
   const long long tile = blockIdx.x;
   const int t0[3] = {(int)(tile / ((long long)ntz * nty)) * NC_TX, (int)((tile / ntz) % nty) * NC_TY, (int)(tile % ntz) * NC_TZ};
   const int nq[3] = {p.nx, p.nqy, p.nqz};
@@ -1255,18 +1257,29 @@ __global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __res
     if (tid == 0) s_next = 0xffffffffu;
     float4 rec[NC_CAND];
     bool in[NC_CAND];
+    {
+      // column of candidate j: the largest col with colbase[col] <= j -- a branch-free binary search with a fixed number of
+      // steps, all NC_CAND searches of a thread advancing together (one LDS latency per step, not per step and candidate)
+      unsigned jj[NC_CAND];
+      int col[NC_CAND];
 #pragma unroll
-    for (int k = 0; k < NC_CAND; ++k) {
-      const unsigned j = cursor + (unsigned)(k * NC_THREADS + tid);
-      in[k] = j < total;
-      if (in[k]) {
-        int a_ = 0, b_ = ncol;   // column of item j: largest col with colbase[col] <= j
-        while (b_ - a_ > 1) {
-          const int m = (a_ + b_) >> 1;
-          if (colbase[m] <= j) a_ = m; else b_ = m;
-        }
-        rec[k] = srec_load(p.srec, colg0[a_] + (j - colbase[a_]));
+      for (int k = 0; k < NC_CAND; ++k) {
+        jj[k] = cursor + (unsigned)(k * NC_THREADS + tid);
+        in[k] = jj[k] < total;
+        col[k] = 0;
       }
+      for (int step = NC_MAXCOL / 2; step >= 1; step >>= 1) {
+        if (step >= 2 * ncol) continue;      // (uniform) beyond the table
+#pragma unroll
+        for (int k = 0; k < NC_CAND; ++k) {
+          const int m = col[k] + step;
+          const unsigned cb = colbase[min(m, NC_MAXCOL)];
+          col[k] = (m < ncol && cb <= jj[k]) ? m : col[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NC_CAND; ++k)
+        if (in[k]) rec[k] = srec_load(p.srec, colg0[col[k]] + (jj[k] - colbase[col[k]]));
     }
 #pragma unroll
     for (int k = 0; k < NC_CAND; ++k) {
