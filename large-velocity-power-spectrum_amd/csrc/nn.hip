@@ -1069,9 +1069,31 @@ __device__ __forceinline__ float nc_readlane(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// Running minima as KEYS: the float32 squared distance with its low NC_KEYBITS mantissa bits replaced by the particle's slot in
+// the staged list -- (d2 & ~mask) | slot.  Squared distances are non-negative, so their bit patterns order like unsigned
+// integers, and one v_min_u32 keeps winner and distance together (no compare + two selects), one v_med3_u32 the runner-up.
+// The price is that the distance is known to 2^-12 only; the settle test of the epilogue works with the bounds that leaves
+// (near ties inside 2.5e-4 go to the exact fallback: 4e5 more points at C3, against a sixth of the loop's instructions).
+// Slot NC_RESOLVED marks a key whose winner has already been looked up (earlier segment; bi[] holds its index).
+constexpr int NC_KEYBITS = 11;
+constexpr unsigned NC_SLOTMASK = (1u << NC_KEYBITS) - 1u;
+constexpr unsigned NC_RESOLVED = NC_SLOTMASK;
+static_assert(NC_SEG < (int)NC_RESOLVED, "staged slots must fit the key's low bits");
+
+__device__ __forceinline__ unsigned nc_bfi(unsigned mask, unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));   // (mask & a) | (~mask & b); hipcc emits and + or
+  return r;
+}
+__device__ __forceinline__ unsigned nc_umed3(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));     // (no builtin for the unsigned median)
+  return r;
+}
+
 // all particles of window class Z0 in this wave's list: entries [beg, end) of ord
 template <int Z0>
-__device__ __forceinline__ void nc_run_class(float (&b1)[NC_TZ], float (&b2)[NC_TZ], int (&bi)[NC_TZ],
+__device__ __forceinline__ void nc_run_class(unsigned (&k1)[NC_TZ], unsigned (&k2)[NC_TZ],
                                              const float4* __restrict__ P, const unsigned short* __restrict__ ord,
                                              unsigned beg, unsigned end, const float* __restrict__ qfz, float qxl, float qyl,
                                              int lane) {
@@ -1079,41 +1101,43 @@ __device__ __forceinline__ void nc_run_class(float (&b1)[NC_TZ], float (&b2)[NC_
   float qz[NC_WIN];
 #pragma unroll
   for (int k = 0; k < NC_WIN; ++k) qz[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qfz[Z0 + k])));
-  float4 nxt = P[ord[beg + (unsigned)lane < end ? beg + (unsigned)lane : beg]];   // 64 list entries, one per lane
+  unsigned nslot = ord[beg + (unsigned)lane < end ? beg + (unsigned)lane : beg];   // 64 list entries, one per lane
+  float4 nxt = P[nslot];
   for (unsigned k0 = beg; k0 < end; k0 += 64) {
     const float4 rec = nxt;
+    const unsigned slotv = nslot;
     {   // the following 64 entries are requested now and land while these are worked through
       const unsigned me = k0 + 64u + (unsigned)lane;
-      nxt = P[ord[me < end ? me : beg]];
+      nslot = ord[me < end ? me : beg];
+      nxt = P[nslot];
     }
     const int cnt = __builtin_amdgcn_readfirstlane((int)min(64u, end - k0));   // (scalar: the loop's exit test stays off the VALU)
     for (int i = 0; i < cnt; ++i) {
       const float px = nc_readlane(rec.x, i), py = nc_readlane(rec.y, i), pz = nc_readlane(rec.z, i);
-      const int idx = __builtin_amdgcn_readlane(__float_as_int(rec.w), i);
+      const unsigned slot = (unsigned)__builtin_amdgcn_readlane((int)slotv, i);
       const float fx = qxl - px, fy = qyl - py;
       const float t2 = fmaf(fy, fy, fx * fx);
+      // (two z per packed instruction -- v_pk_add_f32 / v_pk_fma_f32 -- measured: 14.9 against 14.7 ms, they issue at half rate)
 #pragma unroll
       for (int k = 0; k < NC_WIN; ++k) {
         const float fz = qz[k] - pz;
         const float d2 = fmaf(fz, fz, t2);
-        b2[Z0 + k] = __builtin_amdgcn_fmed3f(b1[Z0 + k], b2[Z0 + k], d2);   // b1 <= b2: the middle one is the new runner-up
-        const bool lt = d2 < b1[Z0 + k];
-        bi[Z0 + k] = lt ? idx : bi[Z0 + k];
-        b1[Z0 + k] = lt ? d2 : b1[Z0 + k];
+        const unsigned key = nc_bfi(NC_SLOTMASK, slot, __float_as_uint(d2));   // (d2 & ~mask) | slot
+        k2[Z0 + k] = nc_umed3(k1[Z0 + k], k2[Z0 + k], key);                  // k1 <= k2: the middle one is the new runner-up
+        k1[Z0 + k] = min(k1[Z0 + k], key);
       }
     }
   }
 }
 
 template <int Z0>
-__device__ __forceinline__ void nc_run_all(float (&b1)[NC_TZ], float (&b2)[NC_TZ], int (&bi)[NC_TZ],
+__device__ __forceinline__ void nc_run_all(unsigned (&k1)[NC_TZ], unsigned (&k2)[NC_TZ],
                                            const float4* __restrict__ P, const unsigned short* __restrict__ ord,
                                            const unsigned* __restrict__ cend, const float* __restrict__ qfz, float qxl,
                                            float qyl, int lane) {
   const unsigned beg = Z0 ? cend[Z0 - 1] : 0u, end = cend[Z0];
-  nc_run_class<Z0>(b1, b2, bi, P, ord, __builtin_amdgcn_readfirstlane(beg), __builtin_amdgcn_readfirstlane(end), qfz, qxl,
-                   qyl, lane);
-  if constexpr (Z0 + 1 < NC_NCLS) nc_run_all<Z0 + 1>(b1, b2, bi, P, ord, cend, qfz, qxl, qyl, lane);
+  nc_run_class<Z0>(k1, k2, P, ord, __builtin_amdgcn_readfirstlane(beg), __builtin_amdgcn_readfirstlane(end), qfz, qxl, qyl, lane);
+  if constexpr (Z0 + 1 < NC_NCLS) nc_run_all<Z0 + 1>(k1, k2, P, ord, cend, qfz, qxl, qyl, lane);
 }
 
 template <typename F, int C>
@@ -1327,12 +1351,12 @@ __global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __res
   NC_STAMP(0);
   unsigned staged = total ? stage(cursor) : 0u;   // the first segment is staged before the 96 accumulator registers exist
   NC_STAMP(1);
-  float b1[NC_TZ], b2[NC_TZ];
-  int bi[NC_TZ];
+  unsigned k1[NC_TZ], k2[NC_TZ];     // smallest and second-smallest key per lattice point of this lane's column
+  int bi[NC_TZ];                     // winner's particle index, looked up at the end of the segment that set it
 #pragma unroll
   for (int z = 0; z < NC_TZ; ++z) {
-    b1[z] = INFINITY;
-    b2[z] = INFINITY;
+    k1[z] = 0x7f800000u | NC_RESOLVED;     // +infinity, nobody's
+    k2[z] = 0x7f800000u | NC_RESOLVED;
     bi[z] = -1;
   }
   auto process = [&](const unsigned n) {
@@ -1381,7 +1405,16 @@ __global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __res
     NC_STAMP(2);
     // (s_setprio 3 outside the class loops / 0 inside -- so that the latency-bound phases never queue behind another wave's
     // VALU stream -- measured: 18.5 against 18.4 ms, no effect)
-    nc_run_all<0>(b1, b2, bi, P, order[wv], cls[wv], qf[2], qxl, qyl, lane);
+    nc_run_all<0>(k1, k2, P, order[wv], cls[wv], qf[2], qxl, qyl, lane);
+    // winners set in this segment: their particle index, while the staged list still holds it
+#pragma unroll
+    for (int z = 0; z < NC_TZ; ++z) {
+      const unsigned slot = k1[z] & NC_SLOTMASK;
+      if (slot != NC_RESOLVED) {
+        bi[z] = __float_as_int(P[slot].w);
+        k1[z] |= NC_RESOLVED;
+      }
+    }
     NC_STAMP(3);
   };
   process(staged);
@@ -1408,9 +1441,11 @@ __global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __res
     for (int z = 0; z < NC_TZ; ++z) {
       // settled: the winner's whole screen lies inside the sphere of radius R (every particle that could beat or tie it was
       // evaluated) and the runner-up lies outside that screen (the float32 winner is the exact one)
-      const float rb = sqrtf(b1[z]) * 1.000001f + 2.f * err;
+      // (the keys hold the distances to 2^-12: b1 from above, b2 from below)
+      const float b1hi = __uint_as_float(k1[z] | NC_SLOTMASK), b2lo = __uint_as_float(k2[z] & ~NC_SLOTMASK);
+      const float rb = sqrtf(b1hi) * 1.000001f + 2.f * err;
       const float screen = rb * rb * 1.000001f;
-      const bool ok = bi[z] >= 0 && screen <= c_init && b2[z] > screen;
+      const bool ok = bi[z] >= 0 && screen <= c_init && b2lo > screen;
       if (!ok && z < nt[2] && col_live) open |= 1u << z;
       img[lane * 33 + z] = max(bi[z], 0);
     }
