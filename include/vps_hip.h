@@ -279,9 +279,12 @@ int vps_deposit_fft_z(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const f
  *   vps_count_in_slab                       that number, with the deposit's own bit-exact cell rule (one pass over the
  *                                           positions, blocks; < 0: error);
  *   vps_deposit_fft_z_workspace_bytes_slab  workspace for np particles of which at most np_slab lie in the slab: no per-input
- *                                           key array, record arrays of np_slab entries (C5 on 8 ranks: 52 GB -> 6 GB);
- *   vps_deposit_fft_z_slab                  vps_deposit_fft_z on such a workspace; VPS_ERR_ARG if more than np_slab particles
- *                                           turn out to lie inside (checked before anything is written past the bound). */
+ *                                           key array, compact {key, payload} and record arrays of np_slab entries (C5 on 8
+ *                                           ranks: 52 GB -> 9 GB); the slab's particles are filtered into them by one pass
+ *                                           over the positions, the sort runs on the compact arrays only;
+ *   vps_deposit_fft_z_slab                  vps_deposit_fft_z on such a workspace; VPS_ERR_ARG if the slab holds more particles
+ *                                           than the workspace has room for (np_slab + the filter pass's block slack; checked
+ *                                           before anything is written past it). */
 int64_t vps_count_in_slab(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, int64_t np, int N, double Lbox, int x0, int nx);
 size_t vps_deposit_fft_z_workspace_bytes_slab(int64_t np, int64_t np_slab, int N, int nx);
 int vps_deposit_fft_z_slab(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,

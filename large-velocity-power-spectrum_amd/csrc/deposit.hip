@@ -252,7 +252,147 @@ __global__ void __launch_bounds__(SORT_THREADS)
         key = (K)brick * g.cells + loc;
         atomicAdd(&sort_lds[brick >> g.gshift], 1u);
       }
-      if (keys) keys[i] = key;     // (NULL: the scatter pass locates the particles again -- slab-sized workspaces)
+      keys[i] = key;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < g.ngroups; i += SORT_THREADS)
+    table[(long long)i * g.nchunks + blockIdx.x] = sort_lds[i];
+}
+
+// ---- slab compaction ---------------------------------------------------------------------------------------------------
+// A rank that holds a REPLICATED particle set but deposits one x-slab of it (scripts/parallel_optimized.py:272-276 loads the
+// whole snapshot on every rank) first filters: one pass over the positions keeps the particles whose cell lies in the slab and
+// writes their {key, [rho v, rho]} to compact arrays -- a workgroup reserves its output range with ONE global atomic.  The
+// two-level sort then runs on the compact arrays only: its tables, chunks and records are sized for the slab, and the seven
+// eighths of the particles that belong to other ranks are read once instead of twice.
+// 256 threads, four consecutive particles per thread: their 12 coordinates are three 16-byte loads of one contiguous 12 KB
+// block per workgroup; [rho v, rho] of the ones inside is requested BEFORE the workgroup's output range is reserved, so that
+// those loads and the atomic's round trip overlap.
+constexpr int COMPACT_THREADS = 256;
+constexpr int COMPACT_ITEMS = 4;
+constexpr int COMPACT_BLOCK = 2048;            // output slots reserved per atomic (>= the particles of one trip)
+constexpr int COMPACT_MAXGRID = 2048;          // workgroups of the compaction launch (each may leave one block partly unused)
+template <typename F, typename K>
+__global__ void __launch_bounds__(COMPACT_THREADS)
+    slab_compact_kernel(const F* __restrict__ pos, const float* __restrict__ vel, const float* __restrict__ rho, long long np,
+                        F lcell, F nsize, Bricks b, SortGeom g, K* __restrict__ ckeys, float4* __restrict__ cpay,
+                        unsigned long long* __restrict__ counter, long long cap) {
+  __shared__ unsigned wcount[COMPACT_THREADS / 64];
+  __shared__ unsigned long long blk_next;        // the block reserved for the part of a trip that does not fit the current one
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // Output slots come in BLOCKS of COMPACT_BLOCK reserved with one global atomic each (a returning atomic on one word peaks
+  // near 90 per microsecond: one per trip -- 10^6 of them at 10^9 particles -- would take longer than reading the particles).
+  // A trip whose records do not fit the rest of the current block spills into the next; what a workgroup leaves unused at the
+  // end is filled with invalid keys, which the sort skips.
+  unsigned long long blk_base = 0;               // (uniform over the workgroup, kept in registers)
+  unsigned blk_used = COMPACT_BLOCK;             // nothing reserved yet
+  constexpr long long PER = (long long)COMPACT_THREADS * COMPACT_ITEMS;
+  const long long nchunk = (np + PER - 1) / PER;
+  for (long long c = blockIdx.x; c < nchunk; c += gridDim.x) {
+    const long long i0 = c * PER + (long long)threadIdx.x * COMPACT_ITEMS;      // this thread's first particle
+    F q[3 * COMPACT_ITEMS];
+    if (i0 + COMPACT_ITEMS <= np) {
+      if constexpr (sizeof(F) == 4) {
+        const float4* src = reinterpret_cast<const float4*>(pos + i0 * 3);       // (i0 * 3 floats = a multiple of 48 bytes)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float4 v4 = src[k];
+          q[4 * k] = v4.x; q[4 * k + 1] = v4.y; q[4 * k + 2] = v4.z; q[4 * k + 3] = v4.w;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3 * COMPACT_ITEMS; ++k) q[k] = pos[i0 * 3 + k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3 * COMPACT_ITEMS; ++k) q[k] = (i0 * 3 + k < np * 3) ? pos[i0 * 3 + k] : F(0);
+    }
+    K key[COMPACT_ITEMS];
+    bool in[COMPACT_ITEMS];
+    float4 pay[COMPACT_ITEMS];
+    unsigned mine = 0;
+#pragma unroll
+    for (int k = 0; k < COMPACT_ITEMS; ++k) {
+      const long long i = i0 + k;
+      const int cx = cell_of<F>(q[3 * k], lcell, nsize) - b.x0;
+      in[k] = i < np && cx >= 0 && cx < b.nx;
+      key[k] = 0;
+      if (in[k]) {
+        const int cy = cell_of<F>(q[3 * k + 1], lcell, nsize), cz = cell_of<F>(q[3 * k + 2], lcell, nsize);
+        in[k] = (unsigned)cy < (unsigned)b.N && (unsigned)cz < (unsigned)b.N;      // NaN / inf: nowhere (as `locate`)
+        if (in[k]) {
+          const int ix = cx / b.bx, iy = cy / b.by, iz = cz / b.bz;
+          const unsigned brick = (unsigned)((ix * b.nby + iy) * b.nbz + iz);
+          const unsigned loc = (unsigned)(((cx - ix * b.bx) * b.by + (cy - iy * b.by)) * b.bz + (cz - iz * b.bz));
+          key[k] = (K)brick * g.cells + loc;
+          const float r = rho[i];
+          pay[k] = make_float4(vel[i * 3 + 0] * r, vel[i * 3 + 1] * r, vel[i * 3 + 2] * r, r);
+          ++mine;
+        }
+      }
+    }
+    // slots: thread-major inside the workgroup (a thread's particles are consecutive), one atomic per workgroup and trip
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    if (lane == 63) wcount[wave] = incl;
+    __syncthreads();
+    unsigned before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < COMPACT_THREADS / 64; ++w) {
+      const unsigned t = wcount[w];
+      if (w < wave) before += t;
+      total += t;
+    }
+    const bool spill = blk_used + total > (unsigned)COMPACT_BLOCK;        // (uniform; total <= PER <= COMPACT_BLOCK)
+    if (spill && threadIdx.x == 0) blk_next = atomicAdd(counter, (unsigned long long)COMPACT_BLOCK);
+    __syncthreads();
+    const unsigned long long nb = spill ? blk_next : blk_base;
+    unsigned p_ = before + incl - mine;            // this thread's first record inside the trip
+#pragma unroll
+    for (int k = 0; k < COMPACT_ITEMS; ++k) {
+      if (in[k]) {
+        const unsigned at = blk_used + p_;
+        const unsigned long long slot = at < (unsigned)COMPACT_BLOCK ? blk_base + at : nb + (at - COMPACT_BLOCK);
+        if ((long long)slot < cap) {
+          ckeys[slot] = key[k];
+          cpay[slot] = pay[k];
+        }
+        ++p_;
+      }
+    }
+    if (spill) {
+      blk_used = blk_used + total - COMPACT_BLOCK;
+      blk_base = nb;
+    } else {
+      blk_used += total;
+    }
+    __syncthreads();   // wcount / blk_next are rewritten by the next trip
+  }
+  // the unused tail of the last block: invalid keys
+  if (blk_used < (unsigned)COMPACT_BLOCK)
+    for (unsigned at = blk_used + threadIdx.x; at < (unsigned)COMPACT_BLOCK; at += COMPACT_THREADS)
+      if ((long long)(blk_base + at) < cap) ckeys[blk_base + at] = sort_invalid<K>();
+}
+
+// level-1 histogram of keys that are already there (the compacted slab)
+template <typename K>
+__global__ void __launch_bounds__(SORT_THREADS)
+    sort_hist_keys_kernel(const K* __restrict__ keys, long long n, SortGeom g, unsigned* __restrict__ table) {
+  extern __shared__ unsigned sort_lds[];
+  for (int i = threadIdx.x; i < g.ngroups; i += SORT_THREADS) sort_lds[i] = 0;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * SORT_CHUNK;
+#pragma unroll 4
+  for (int k = 0; k < SORT_ITEMS; ++k) {
+    const long long i = base + (long long)k * SORT_THREADS + threadIdx.x;
+    if (i < n) {
+      const K key = keys[i];
+      if (key != sort_invalid<K>()) atomicAdd(&sort_lds[sort_bucket_of<K>(key, g) >> g.gshift], 1u);   // (block tails of the compaction)
     }
   }
   __syncthreads();
@@ -364,15 +504,11 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned* a, int n, uns
 // of 64 scattered dwords per instruction.  Consecutive chunks own adjacent runs of every group:
 // they are dealt to the SAME XCD (blockIdx % 8, speed only) so that its L2 can merge the partly
 // written lines at run boundaries.
-// RECOMP: there is no keys[] array (8 bytes per INPUT particle -- 8 GB of a rank's workspace at 1e9 replicated particles of
-// which an eighth lie in its slab): the particles are located again from their positions, which costs the same 12 bytes of
-// reads that the keys cost 8 of.
-template <int C, bool RHOV, typename K, typename F, bool RECOMP>
+template <int C, bool RHOV, typename K>
 __global__ void __launch_bounds__(SORT_THREADS)
     sort_scatter_staged_kernel(const K* __restrict__ keys, const float* __restrict__ payload,
                                const float* __restrict__ rho, long long np, SortGeom g,
-                               const unsigned* __restrict__ table_start, unsigned* __restrict__ rec1,
-                               const F* __restrict__ pos, F lcell, F nsize, Bricks b) {
+                               const unsigned* __restrict__ table_start, unsigned* __restrict__ rec1) {
   constexpr int W = sort_rec1_words(C);
   extern __shared__ unsigned sort_lds[];
   unsigned* gbase = sort_lds;                        // [ngroups] first global slot of this chunk's run
@@ -395,12 +531,7 @@ __global__ void __launch_bounds__(SORT_THREADS)
 #pragma unroll
   for (int k = 0; k < SORT_ITEMS; ++k) {
     const long long i = base + (long long)k * SORT_THREADS + threadIdx.x;
-    if constexpr (RECOMP) {
-      unsigned brick, loc;
-      key[k] = (i < np && locate<F>(pos, i, lcell, nsize, b, brick, loc)) ? (K)brick * g.cells + loc : sort_invalid<K>();
-    } else {
-      key[k] = (i < np) ? keys[i] : sort_invalid<K>();
-    }
+    key[k] = (i < np) ? keys[i] : sort_invalid<K>();
     if (key[k] != sort_invalid<K>()) load_payload<C, RHOV>(payload, rho, i, val[k]);
   }
 #pragma unroll
@@ -787,7 +918,9 @@ struct DepLayout {
   size_t count, start, tiles, keys, ranks, records, table, table_start, table_tiles, rec1, total;
   long long nbricks;
   long long cap;    // records the workspace has room for: np, or the caller's bound on the particles inside the slab
-  bool recompute;   // cap < np: no keys[] array either (sort_scatter_staged_kernel<..., RECOMP>)
+  long long cap_in; // entries of the compacted input arrays (cap + the block tails of slab_compact_kernel)
+  bool recompute;   // cap < np: the slab's particles are compacted first (slab_compact_kernel); keys[] / cpay hold cap entries
+  size_t cpay, counter;
   bool two_level;
   bool wide_keys;   // bucket * cells + cell does not fit 32 bits: 64-bit keys[] (the level-1 records stay 32-bit, see SortGeom)
   SortGeom geom;
@@ -827,27 +960,43 @@ DepLayout dep_layout(int64_t np, int C, const Bricks& b, int64_t np_cap = -1) {
   g.gshift = 3;
   while (((l.nbricks + (1ll << g.gshift) - 1) >> g.gshift) > sort_target_groups()) ++g.gshift;
   g.ngroups = (int)((l.nbricks + (1ll << g.gshift) - 1) >> g.gshift);
-  g.nchunks = (np + SORT_CHUNK - 1) / SORT_CHUNK;
+  g.nchunks = (np + SORT_CHUNK - 1) / SORT_CHUNK;     // (slab-sized workspaces: re-set below)
   l.wide_keys = (unsigned long long)l.nbricks * (unsigned long long)b.cells >= 0xffffffffull;
   l.two_level = !sort_force_atomic() && g.gshift <= 12 && l.nbricks < 0x7fffffffLL &&
                 ((unsigned long long)b.cells << g.gshift) < 0xffffffffull;
-  const long long ntable = (long long)g.ngroups * g.nchunks;
-  l.recompute = np_cap >= 0 && np_cap < np && l.two_level && sort_staged() && sort_staged_lds(g, C) <= 160 * 1024;
+  l.recompute = np_cap >= 0 && np_cap < np && l.two_level && sort_staged() && sort_staged_lds(g, C) <= 160 * 1024 && C == 4;
   l.cap = l.recompute ? np_cap : np;
+  // compacted arrays: the slab's particles + one partly used block per workgroup of the compaction launch
+  {
+    const long long trips = (np + (long long)COMPACT_THREADS * COMPACT_ITEMS - 1) / ((long long)COMPACT_THREADS * COMPACT_ITEMS);
+    const long long slack = std::min<long long>(trips, COMPACT_MAXGRID) * COMPACT_BLOCK;
+    if (l.recompute && l.cap + slack >= np / 2) {     // nothing to gain: sort all particles in place, as without a bound
+      l.recompute = false;
+      l.cap = np;
+    }
+    l.cap_in = l.recompute ? l.cap + slack : l.cap;
+  }
+  if (l.recompute) g.nchunks = (l.cap_in + SORT_CHUNK - 1) / SORT_CHUNK;     // the sort sees the compacted particles only
+  const long long ntable = (long long)g.ngroups * g.nchunks;
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t off = 0;
   l.count = off;   off = align(off + sizeof(unsigned) * l.nbricks);
   l.start = off;   off = align(off + sizeof(unsigned) * (l.nbricks + 1));
   l.tiles = off;   off = align(off + sizeof(unsigned) * (scan_tiles(l.nbricks) + 1));
-  l.keys = off;    off = align(off + (l.recompute ? 0 : (size_t)np * sizeof(unsigned long long)));
-  l.ranks = off;   off = align(off + (size_t)l.cap * sizeof(unsigned));
-  l.records = off; off = align(off + (size_t)l.cap * (C + 1) * sizeof(unsigned));
+  l.keys = off;    off = align(off + (size_t)l.cap_in * sizeof(unsigned long long));
+  l.cpay = l.counter = off;
+  if (l.recompute) {
+    l.cpay = off;    off = align(off + (size_t)l.cap_in * sizeof(float4));
+    l.counter = off; off = align(off + sizeof(unsigned long long));
+  }
+  l.ranks = off;   off = align(off + (size_t)l.cap_in * sizeof(unsigned));
+  l.records = off; off = align(off + (size_t)l.cap_in * (C + 1) * sizeof(unsigned));
   l.table = l.table_start = l.table_tiles = l.rec1 = off;
   if (l.two_level) {
     l.table = off;        off = align(off + sizeof(unsigned) * (ntable + 1));
     l.table_start = off;  off = align(off + sizeof(unsigned) * (ntable + 1));
     l.table_tiles = off;  off = align(off + sizeof(unsigned) * (scan_tiles(ntable) + 1));
-    l.rec1 = off;         off = align(off + (size_t)l.cap * sort_rec1_words(C) * sizeof(unsigned));
+    l.rec1 = off;         off = align(off + (size_t)l.cap_in * sort_rec1_words(C) * sizeof(unsigned));
   }
   l.total = off;
   return l;
@@ -878,31 +1027,53 @@ int sort_into_buckets(vps_ctx* ctx, const F* pos, const float* payload, const fl
     if (l.recompute && !staged) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "slab-sized sort workspace needs the LDS-staged scatter");
     auto level1 = [&](auto* keys) -> int {
       typedef typename std::remove_pointer<decltype(keys)>::type K;
-      hipLaunchKernelGGL((sort_hist_kernel<F, K>), dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1, ctx->stream, pos,
-                         (long long)np, lcell, nsz, b, g, l.recompute ? (K*)nullptr : keys, table);
-      launch_exclusive_scan(ctx->stream, table, (long long)g.ngroups * g.nchunks, table_tiles, table_start);
+      long long n_sort = np;                   // particles the sort proper sees
+      const float* pay = payload;
       if (l.recompute) {
-        // the scan's total is the number of particles inside the slab: it must fit the caller's bound
-        unsigned inside = 0;
-        VPS_HIP_CHECK(ctx, hipMemcpyAsync(&inside, table_start + (long long)g.ngroups * g.nchunks, sizeof(unsigned),
-                                          hipMemcpyDeviceToHost, ctx->stream));
-        VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if ((long long)inside > l.cap)
-          return vps_fail(ctx, VPS_ERR_ARG, "%u particles lie inside the slab, the workspace was sized for %lld (vps_count_in_slab)",
-                          inside, l.cap);
+        // filter first: {key, [rho v, rho]} of the slab's particles, compact
+        if constexpr (RHOV) {
+          unsigned long long* counter = reinterpret_cast<unsigned long long*>(work + l.counter);
+          float4* cpay = reinterpret_cast<float4*>(work + l.cpay);
+          VPS_HIP_CHECK(ctx, hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
+          const long long nch = (np + (long long)COMPACT_THREADS * COMPACT_ITEMS - 1) / ((long long)COMPACT_THREADS * COMPACT_ITEMS);
+          const unsigned cgrid = (unsigned)std::min<long long>(std::min<long long>(nch, (long long)ctx->num_cu * 8), COMPACT_MAXGRID);
+          hipLaunchKernelGGL((slab_compact_kernel<F, K>), dim3(cgrid), dim3(COMPACT_THREADS), 0, ctx->stream, pos, payload, rho,
+                             (long long)np, lcell, nsz, b, g, keys, cpay, counter, l.cap_in);
+          unsigned long long reserved = 0;      // slots handed out: the slab's particles + at most one partly used block per workgroup
+          VPS_HIP_CHECK(ctx, hipMemcpyAsync(&reserved, counter, sizeof(reserved), hipMemcpyDeviceToHost, ctx->stream));
+          VPS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+          if ((long long)reserved > l.cap_in)
+            return vps_fail(ctx, VPS_ERR_ARG, "more particles lie inside the slab than the workspace was sized for (%lld; vps_count_in_slab)",
+                            l.cap);
+          n_sort = (long long)reserved;
+          pay = reinterpret_cast<const float*>(cpay);
+          if (n_sort == 0) {
+            VPS_HIP_CHECK(ctx, hipMemsetAsync(start, 0, sizeof(unsigned) * (l.nbricks + 1), ctx->stream));
+            return 1;     // (nothing to sort: start[] is all zero)
+          }
+          hipLaunchKernelGGL((sort_hist_keys_kernel<K>), dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1, ctx->stream,
+                             (const K*)keys, n_sort, g, table);
+        } else {
+          return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "slab-sized sort workspace: [rho v, rho] records only");
+        }
+      } else {
+        hipLaunchKernelGGL((sort_hist_kernel<F, K>), dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1, ctx->stream, pos,
+                           (long long)np, lcell, nsz, b, g, keys, table);
       }
+      launch_exclusive_scan(ctx->stream, table, (long long)g.ngroups * g.nchunks, table_tiles, table_start);
       if (staged) {
         const unsigned grid = (unsigned)(8 * ((g.nchunks + 7) / 8));
         auto go = [&](auto kern) -> int {
           if (lds_staged > 64 * 1024)
             VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
-          hipLaunchKernelGGL(kern, dim3(grid), dim3(SORT_THREADS), lds_staged, ctx->stream, (const K*)keys, payload, rho,
-                             (long long)np, g, table_start, rec1, pos, lcell, nsz, b);
+          hipLaunchKernelGGL(kern, dim3(grid), dim3(SORT_THREADS), lds_staged, ctx->stream, (const K*)keys, pay, rho,
+                             n_sort, g, table_start, rec1);
           return VPS_OK;
         };
-        const int rcs = l.recompute ? go(sort_scatter_staged_kernel<C, RHOV, K, F, true>)
-                                    : go(sort_scatter_staged_kernel<C, RHOV, K, F, false>);
+        int rcs;
+        if constexpr (C == 4) rcs = l.recompute ? go(sort_scatter_staged_kernel<4, false, K>) : go(sort_scatter_staged_kernel<C, RHOV, K>);
+        else rcs = go(sort_scatter_staged_kernel<C, RHOV, K>);
         if (rcs) return rcs;
       } else {
         hipLaunchKernelGGL((sort_scatter_kernel<C, RHOV, K>), dim3((unsigned)g.nchunks), dim3(SORT_THREADS), lds1,
@@ -913,6 +1084,7 @@ int sort_into_buckets(vps_ctx* ctx, const F* pos, const float* payload, const fl
     // (the keys[] region holds 8 bytes per particle either way: the atomic-rank path's keys are 64-bit)
     const int rc1 = l.wide_keys ? level1(reinterpret_cast<unsigned long long*>(work + l.keys))
                                 : level1(reinterpret_cast<unsigned*>(work + l.keys));
+    if (rc1 == 1) return VPS_OK;     // (empty slab)
     if (rc1) return rc1;
     hipLaunchKernelGGL(sort_fine_kernel<C>, dim3((unsigned)g.ngroups), dim3(FINE_THREADS), lds2, ctx->stream, rec1,
                        g, table_start, start, records);

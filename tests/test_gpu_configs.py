@@ -309,26 +309,43 @@ def test_config5_one_rank_share(K):
 
 
 def test_slab_sized_sort_workspace(K):
-    """vps_count_in_slab + vps_deposit_fft_z_slab: the same z images as the plain call from a workspace sized for the slab's
-    particles only; a bound that is too small is refused before anything is written."""
-    from vpower import device, _ffi
-    N, Np, L, x0, nx = 256, 400_000, 1.0, 96, 32
-    pos, vel, mass, dens = synth(8, Np, L)
-    pos[:1000] = np.nan                                     # never inside any slab
-    d = [K.to_device(a) for a in (pos, vel, dens)]
-    inside = K.count_in_slab(d[0], N, L, x0, nx)
-    cx = orc.cell_index(pos[1000:], N, L)[:, 0]
-    assert inside == int(np.count_nonzero((cx >= x0) & (cx < x0 + nx)))
+    """vps_count_in_slab + vps_deposit_fft_z_slab: a rank that holds a replicated particle set filters the particles of its
+    slab into compact arrays (slab_compact_kernel: block reservations, invalid keys in the block tails) and sorts only those --
+    same z images as the plain call, from a workspace sized for the slab.  3e7 particles, an eighth of them in the slab."""
+    from vpower import device
+    N, Np, L, x0, nx = 512, 30_000_000, 1.0, 192, 64
+    gen = torch.Generator(device=K.device)
+    gen.manual_seed(11)
+    dpos = torch.rand((Np, 3), dtype=torch.float32, device=K.device, generator=gen)
+    dpos[:1000] = float("nan")                              # never inside any slab
+    dvel = torch.randn((Np, 3), dtype=torch.float32, device=K.device, generator=gen)
+    drho = torch.rand((Np,), dtype=torch.float32, device=K.device, generator=gen) + 0.5
+    inside = K.count_in_slab(dpos, N, L, x0, nx)
+    cx = K.cell_index(dpos[1000:], N, L)[:, 0]              # (bit-exact against the oracle: test_cell_index_bit_exact)
+    assert inside == int(((cx >= x0) & (cx < x0 + nx)).sum().item())
+    del cx
+    plain = int(K.lib.vps_deposit_fft_z_workspace_bytes(Np, N, nx))
+    slab = int(K.lib.vps_deposit_fft_z_workspace_bytes_slab(Np, inside, N, nx))
+    assert slab < plain // 2
     for q in (device.VELOCITY, device.ENERGY):
-        a = K.deposit_fft_z(d[0], d[1], d[2], N, L, x0, nx, q)
+        a = K.deposit_fft_z(dpos, dvel, drho, N, L, x0, nx, q)
         K._work.clear()
-        b = K.deposit_fft_z(d[0], d[1], d[2], N, L, x0, nx, q, slab_particles=inside)
+        b = K.deposit_fft_z(dpos, dvel, drho, N, L, x0, nx, q, slab_particles=inside)
         tol = 1e-5 * float(a.abs().square().mean().sqrt().item())
         assert float((a - b).abs().max().item()) < tol
-    assert int(K.lib.vps_deposit_fft_z_workspace_bytes_slab(Np, inside, N, nx)) < int(K.lib.vps_deposit_fft_z_workspace_bytes(Np, N, nx)) // 3
-    K._work.clear()
-    with pytest.raises(_ffi.VpsError, match="inside the slab"):
-        K.deposit_fft_z(d[0], d[1], d[2], N, L, x0, nx, device.VELOCITY, slab_particles=inside - 1)
+        # a generous bound changes nothing; a second quantity re-uses the compacted sort
+        tok = K.fused_token()
+        c = K.deposit_fft_z(dpos, dvel, drho, N, L, x0, nx, q, slab_particles=inside, reuse_sort=tok)
+        assert float((a - c).abs().max().item()) < tol
+        K._work.clear()
+    # small inputs (nothing to gain) take the plain route under the same entry point
+    pos, vel, mass, dens = synth(8, 400_000, L)
+    d = [K.to_device(x_) for x_ in (pos, vel, dens)]
+    ins = K.count_in_slab(d[0], 256, L, 96, 32)
+    assert ins == int(np.count_nonzero((lambda c_: (c_ >= 96) & (c_ < 128))(orc.cell_index(pos, 256, L)[:, 0])))
+    a = K.deposit_fft_z(d[0], d[1], d[2], 256, L, 96, 32, device.VELOCITY)
+    b = K.deposit_fft_z(d[0], d[1], d[2], 256, L, 96, 32, device.VELOCITY, slab_particles=ins)
+    assert float((a - b).abs().max().item()) < 1e-5 * float(a.abs().square().mean().sqrt().item())
     _free(K)
 
 
