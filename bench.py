@@ -420,9 +420,11 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     step_kernel_ms = {k: v[1] / nst for k, v in tim.items() if v[0]}
     # y and x launches come as main launches (whole fields, or kz chunks of them) and small Nyquist-plane launches
     # (one plane against hundreds): the main ones are those within a factor 8 of the longest
-    def main_of(v):
-        return v[v * 8.0 >= v.max()] if len(v) else v
-    main = {"fft_y": main_of(per["fft_y"]), "fft_x": main_of(per["fft_x"]), "fft_z": per["fft_z"], "nn_query": main_of(per["nn_query"])}
+    def main_of(v, within=8.0):
+        return v[v * within >= v.max()] if len(v) else v
+    # (NN search: the search kernel proper; the exact fallback for the points it leaves open is its own, much shorter launch --
+    #  both are in kernel_ms_per_step["nn_query"])
+    main = {"fft_y": main_of(per["fft_y"]), "fft_x": main_of(per["fft_x"]), "fft_z": per["fft_z"], "nn_query": main_of(per["nn_query"], 2.0)}
     Nps = Np / G      # particles inside one rank's slab (uniform positions)
     # algorithmic HBM bytes of the main launches of ONE step, per kernel family (DESIGN.md "Kernels"): what the kernels
     # have to move -- rows (ky, kz) beyond the last shell edge are neither written by the y pass nor read by the x pass
@@ -445,7 +447,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     grid_ms = step_kernel_ms.get("deposit", 0.0) + step_kernel_ms.get("algebra", 0.0) \
         + step_kernel_ms.get("nn_build", 0.0) + step_kernel_ms.get("nn_query", 0.0)
     traffic = None
-    tr_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    tr_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if os.path.exists(tr_path) and world == 1 and G == 1:
         try:
             traffic = json.load(open(tr_path)).get(cfg, {}).get(dom)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 --pmc passes of tools/gpu_profile_round.sh:
-   python tools/pmc_summary.py gpurun_out/prof/r02 profiles/r02
+   python tools/pmc_summary.py gpurun_out/prof/r03 profiles/r03
    -> <dst>_pmc_summary.json   per kernel: the launch with the largest FETCH_SIZE / WRITE_SIZE (raw KB), corrected HBM
                                bytes, VALUBusy / LDSBankConflict / MemUnitStalled of its longest launch
       <dst>_pmc_traffic.json   {config: {kernel family: HBM bytes of its main launch}} -- what bench.py copies into
@@ -53,7 +53,7 @@ fam = {
     "C2": {"fft_z": "pencil_fft_z_kernel<256, 16, false>", "fft_y": "fft_transpose_pass<512, 16, false, true, false",
            "fft_x": "fft_x_pass<512, 8, 0"},
     "C3": {"fft_z": "fft_transpose_pass<512, 8, true", "fft_y": "fft_transpose_pass_wide<1024, 8, 64, true>",
-           "fft_x": "fft_x_pass<1024, 4, 0", "nn_query": "nn_scatter_kernel<float, 4>"},
+           "fft_x": "fft_x_pass<1024, 4, 0", "nn_query": "nn_column_kernel<float, 4>"},
 }
 traffic = {"_note": "HBM bytes of the MAIN (largest) launch of each hot kernel, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in "
                     "separate passes over `python3 bench.py` (tools/gpu_profile_round.sh), FETCH_SIZE doubled per "
