@@ -6,11 +6,13 @@
 // contraction), lowest original particle index on exact ties -- the rule the oracle
 // states, so indices are bit exact.
 //
-// Method: counting-sort the particles into an M^3 cell list spanning their bounding
-// box (about 1.5 particles per cell), then
-//   * uniformly spaced lattices (both reference lattices): nn_scatter_kernel -- a 16^3 tile of
-//     lattice points keeps its running minima in LDS and every nearby particle lowers the
-//     minima inside its own R-box; the few points this cannot settle (voids, near-ties)
+// Method: sort the particles into an M^3 cell list spanning their bounding box (about 1.5
+// particles per cell; two-level LDS bucket sort, nb_* kernels), then
+//   * uniformly spaced lattices (both reference lattices): nn_column_kernel where the lattice is
+//     about as fine as the particles are dense -- a lane keeps the minima of a column of 32 lattice
+//     points in registers and a wave walks the nearby particles --, else nn_scatter_kernel -- a
+//     16^3 tile of lattice points keeps its running minima in LDS and every nearby particle lowers
+//     the minima inside its own R-box; the few points these cannot settle (voids, near-ties)
 //     are finished by nn_fallback_kernel;
 //   * any other lattice axes: nn_query_kernel -- one thread per lattice point, a wave-wide
 //     staged union of candidate cells, then Chebyshev rings of cells from global memory
@@ -1011,9 +1013,9 @@ __global__ void __launch_bounds__(NT_THREADS) nn_scatter_kernel(const F* __restr
 // the 8 z-points of the particle's z-window [z0, z0 + 8), which is where its R-ball can reach (R <= (3.5 - slack) h_z
 // makes 8 points enough).  The window start decides which registers are touched, so the wave's list is counting-sorted
 // by z0 first and each of the 25 classes runs its own straight-line code with static register indices: per (particle,
-// z) one subtract, one fma, a median-of-three (new runner-up), a compare and two selects -- no LDS traffic, no atomics,
-// no divergence, results independent of any order.  About 90 pair evaluations per lattice point instead of the scatter
-// kernel's 12, at a tenth of the cost each.
+// z) one subtract, one fma, and on the KEY (distance bits | staged slot, see NC_KEYBITS) a bit-field insert, an unsigned
+// median-of-three (new runner-up) and an unsigned minimum -- no LDS traffic, no atomics, no divergence, results independent
+// of any order.  About 90 pair evaluations per lattice point instead of the scatter kernel's 12, at a tenth of the cost each.
 // Exactness is argued as for the scatter kernel: every particle within R of a point has been evaluated for it (the
 // staged region covers the tile + R, a wave's list every disc that meets its patch, a window every z within R); the
 // point is settled when the winner's screen (sqrt(b1) + 2 err)^2 lies inside R^2 and the runner-up outside that
