@@ -529,7 +529,16 @@ def test_nn_scatter_and_query_centric_kernels_agree(K):
         outs.append(o)
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0].reshape(4, -1), pay4[torch.as_tensor(ref, device=K.device).long()].T)
-    # descending z axis, x-slab [8, 24): still the scatter kernel
+    # very few particles on a fine lattice: by default the scatter kernel; the column kernel forced -- almost every point is
+    # beyond its capped radius and goes to the exact fallback, and with more tiles than cells the radii are computed in the kernel
+    few = rng.random((50, 3)).astype(np.float32)
+    axf = orc.lattice_axes_library(L, 64)
+    reff = orc.exact_nn_lattice(few, axf, axf, axf)
+    for col in (None, 1):
+        with _ffi.option("nn_column", col):
+            _, ifew = K.nn_resample(K.to_device(few), K.zeros((50, 1), torch.float32), (axf, axf, axf), 0, 64, want_index=True)
+        assert np.array_equal(ifew.cpu().numpy().ravel(), reff), col
+    # descending z axis, x-slab [8, 24): uniform, so still one of the two lattice kernels
     axr = ax[::-1].copy()
     _, i3 = K.nn_resample(dpos, payload, (ax, ax, axr), 8, 16, want_index=True)
     assert np.array_equal(i3.cpu().numpy().ravel(), orc.exact_nn_lattice(pos, ax[8:24], ax, axr))
