@@ -1193,6 +1193,12 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   constexpr bool CANPAIR = FAST && (T >= 2) && (NC >= T) && (NC % T == 0) && (!WSYNC || L <= 32);
   const bool pair = CANPAIR && p.pair;
   constexpr int TH = (T >= 2) ? T / 2 : 1;
+  // A PAIR tile holds TH consecutive |ky|, aligned to TH.  The y passes of a binning-only scope store the rows |ky| <= kcut[kz],
+  // kcut = the exact cut rounded UP to 16 k + 15 (vps_set_binning, api.hip).  Where TH divides 16 (every power-of-two grid from
+  // 128 on) a tile that is transformed lies entirely inside the stored rows.  Elsewhere (TH = 32 on the small grids, TH = 6 on
+  // 3 2^a) a transformed tile may read rows the y pass left unwritten: every mode of such a row has fl(ky^2 + kz^2) >=
+  // thr[nbins], the shell search below puts it at bin == nbins, and the `bin < nbins` guard keeps whatever the row held
+  // (NaN included) out of every sum and count -- tests/test_gpu_configs.py runs the exchange buffers NaN-prefilled for this.
   // tile -> this lane's line, and the loads of its stage-0 inputs
   long long li = 0, lrow = 0;   // line index inside the launch's range, and the row of the input it is read from
   bool live = false, mirrored = false, has_partner = false;
