@@ -1142,7 +1142,10 @@ struct XParams {
 // then walks RL/2 values of |kx|, adds the two mirrored |F|^2 and issues one LDS atomic
 // per |kx|, with no per-element branches (the host checks the table, vps_set_binning).
 template <int NC, int T, int MODE, bool SEG, bool COUNT, bool FAST>
-__global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p) {
+#ifndef VPS_X_MIN_WAVES
+#define VPS_X_MIN_WAVES 1
+#endif
+__global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pass(const XParams p) {
   typedef PlanInfo<NC> PI;
   constexpr int L = PI::L, RL = PI::RL, NT = T * L;
   constexpr int H = RL / 2;   // |kx| values per lane on the FAST path
@@ -1263,6 +1266,27 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L) fft_x_pass(const XParams p
   auto load_line = [&](cf (&v)[RL], int c, int l) {   // l: the lane index (callers inside loops pass an opaque copy)
     constexpr int R = PI::R0, NB = RL / R;
     const cf* base = (c == 0 ? p.in : (c == 1 ? p.in1 : p.in2)) + lrow * p.seglen;
+    if constexpr (SEG && (L % 64 == 0)) {
+      // A wave holds lanes of ONE line here, so the line's base is wave-uniform; and with power-of-two segments of at least L
+      // elements, element x = l + xr (xr = L m + r NC/R, a multiple of L) sits in segment xr >> seg_shift at offset
+      // (xr & segmask) + l with no carry.  Everything but l is then scalar: the loads take an SGPR base and one 32-bit lane
+      // offset instead of a 64-bit multiply-add per element (x pass of a received 2048^3 chunk, 8 segments: 4.22 -> see DESIGN).
+      if (p.seg_shift >= 0 && p.seglen >= L) {
+        const unsigned long long ub = reinterpret_cast<unsigned long long>(base);
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)ub), bhi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
+        const cf* sbase = reinterpret_cast<const cf*>(((unsigned long long)bhi << 32) | blo);
+#pragma unroll
+        for (int m = 0; m < NB; ++m)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int xr = L * m + r * (NC / R);
+            const long long off = (long long)(xr >> p.seg_shift) * p.seg_stride + (xr & segmask);
+            const double raw = live ? __builtin_nontemporal_load(reinterpret_cast<const double*>(&sbase[off + l])) : 0.0;
+            v[m * R + r] = *reinterpret_cast<const cf*>(&raw);
+          }
+        return;
+      }
+    }
 #pragma unroll
     for (int m = 0; m < NB; ++m)
 #pragma unroll
