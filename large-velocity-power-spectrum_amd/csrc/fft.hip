@@ -971,9 +971,21 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
     tc &= TP - 1;
     tidc &= NT - 1;
     __syncthreads();   // rho / previous component's transposed image fully consumed
+    // The accumulator still holds the previous round's totals -- rho ahead of the first velocity component, a component ahead
+    // of the next one (ENERGY) -- and is zero in every cell without a record: the records clear their own cells (a few hundred
+    // 4-byte writes) instead of a dense fill of the whole region (64 - 128 KB at the LDS write rate: 830 - 1500 clk per round).
+    // After a transform the region is FFT scratch and needs the dense fill.
+    const bool sparse_clear = ENERGY ? (c > 0) : (divide && c == 0);
+    if (sparse_clear) {
+#pragma unroll
+      for (int k = 0; k < KR; ++k)
+        if (rloc[k] != 0xffffffffu) acc[rloc[k]] = 0.f;
+      for (unsigned j = tail0; j < e; j += NT) acc[p.records[(size_t)j * 5]] = 0.f;
+    } else {
 #ifndef VPS_ABL_NOZERO
-    for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
+      for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
 #endif
+    }
     __syncthreads();
     const bool rho_round = ENERGY && c == p.ncomp;
     const int word = rho_round ? 4 : 1 + p.chan[c < p.ncomp ? c : 0];
@@ -1553,10 +1565,15 @@ constexpr int transpose_T() {
   if (NC <= 2048) return 8;
   return 4;
 }
+// (4096-point lines, L = 256: ONE line per 256-thread workgroup; two lines -- (ky, N-ky) pairs binned together, 512 threads -- measured
+// slower on the C5 rank share: 17.0 against 13.6 ms)
+#ifndef VPS_X_T_LONG
+#define VPS_X_T_LONG 1
+#endif
 template <int NC>
 constexpr int xpass_T() {
   constexpr int L = Plan<NC>::L;
-  constexpr int t = (256 / L) > 0 ? (256 / L) : 1;
+  constexpr int t = (256 / L) > 1 ? (256 / L) : VPS_X_T_LONG;   // (L = 256: 4096-point lines)
   return (t > 1 && (t & 1)) ? t - 1 : t;   // even, so that a tile holds whole (ky, N-ky) pairs (L = 50 -> 4)
 }
 
