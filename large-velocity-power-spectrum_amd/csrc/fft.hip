@@ -432,6 +432,36 @@ __device__ __forceinline__ void exchange_sync() {
   }
 }
 
+// Second exchange of the 1024-point plan (64 lanes x 16 points, radices 16 x 8 x 8) WITHOUT LDS.  Between the two radix-8 stages
+// element (lane 16 g + c, slot m*8 + 4a + b) of the next stage is element (lane 16 b + c, slot a*8 + 4m + g) of the previous one:
+// the column c inside a row of 16 lanes stays, and for every (a, m) the four registers q = 0..3 at slots a*8 + 4m + q are
+// transposed against the four lane ROWS.  gfx950's v_permlane32_swap (upper half of vdst <-> lower half of vsrc) and
+// v_permlane16_swap (odd rows of vdst <-> even rows of vsrc) do a 4 x 4 row transpose of four registers in four instructions:
+// 32 VALU swaps replace 16 ds_write_b64 + 16 ds_read_b64 and a wave-level sync in a kernel whose LDS pipe is the busiest unit
+// (pencil kernel at C4: SQ_ACTIVE_INST_LDS x 16 waves ~ 90 % of the CU's cycles).  tools/micro/permlane_swap.hip pins the semantics.
+#ifndef VPS_NO_SWAP_EXCHANGE
+#define VPS_SWAP_EXCHANGE 1
+#else
+#define VPS_SWAP_EXCHANGE 0
+#endif
+template <int NC, int L, bool WAVE>
+constexpr bool swap_exchange2() {
+  return VPS_SWAP_EXCHANGE && WAVE && NC == 1024 && L == 64 && PlanInfo<NC>::R0 == 16 && PlanInfo<NC>::R1 == 8 && PlanInfo<NC>::R2 == 8;
+}
+typedef unsigned vps_u2 __attribute__((ext_vector_type(2)));
+// y_b at lane row g = x_g at lane row b (rows of 16 lanes), in place
+__device__ __forceinline__ void rows_transpose4(float& x0, float& x1, float& x2, float& x3) {
+  vps_u2 r;
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x0), __float_as_uint(x2), false, false);
+  x0 = __uint_as_float(r.x); x2 = __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x1), __float_as_uint(x3), false, false);
+  x1 = __uint_as_float(r.x); x3 = __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
+  x0 = __uint_as_float(r.x); x1 = __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x2), __float_as_uint(x3), false, false);
+  x2 = __uint_as_float(r.x); x3 = __uint_as_float(r.y);
+}
+
 // Runs stages 1.. (stage 0 inputs already in v).  On return v holds the spectrum:
 // v[m*RLAST + r] = F[l + L*m + r*NC/RLAST].  L lanes per line (default: the plan's; the persistent transposing pass
 // of the longest lines runs a line on half as many lanes with twice the points each).
@@ -447,10 +477,25 @@ __device__ __forceinline__ void fft_from_regs_l(cf (&v)[NC / L], cf* line, const
     lds_load_stage<NC, L, RL, PI::R1>(v, line, l);
     twiddle_butterfly<NC, L, RL, PI::R1, PI::NS1>(v, tw, l);
     if constexpr (PI::R2 > 1) {
-      exchange_sync<WAVE>();
-      lds_store_stage<NC, L, RL, PI::R1, PI::NS1>(v, line, l);
-      exchange_sync<WAVE>();
-      lds_load_stage<NC, L, RL, PI::R2>(v, line, l);
+      if constexpr (swap_exchange2<NC, L, WAVE>()) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {   // the four (a, m) groups: slots 4 g4 .. 4 g4 + 3
+          rows_transpose4(v[4 * g4].x, v[4 * g4 + 1].x, v[4 * g4 + 2].x, v[4 * g4 + 3].x);
+          rows_transpose4(v[4 * g4].y, v[4 * g4 + 1].y, v[4 * g4 + 2].y, v[4 * g4 + 3].y);
+        }
+        // slot m*8 + 4a + b of the next stage <- transposed slot a*8 + 4m + b: (a, m) = (0, 1) and (1, 0) trade places
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const cf tmp = v[4 + b];
+          v[4 + b] = v[8 + b];
+          v[8 + b] = tmp;
+        }
+      } else {
+        exchange_sync<WAVE>();
+        lds_store_stage<NC, L, RL, PI::R1, PI::NS1>(v, line, l);
+        exchange_sync<WAVE>();
+        lds_load_stage<NC, L, RL, PI::R2>(v, line, l);
+      }
       twiddle_butterfly<NC, L, RL, PI::R2, PI::NS2>(v, tw + PI::TW1, l);
     }
   }
