@@ -62,6 +62,12 @@ def parse_args(argv=None):
                     help="skip the full-size checks of the timed step's tables (exact shell counts, Parseval over all modes)")
     ap.add_argument("--unfused", action="store_true", help="NGP route: separate deposit and z-pass kernels (grid through HBM)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the roofline")
+    ap.add_argument("--decomposition", choices=("slab", "fields"), default="slab",
+                    help="several GPUs: 'slab' = 1-D x-slabs with one all-to-all per field (BASELINE's C4 / C5 configuration, the "
+                         "default and the reported value); 'fields' = every rank transforms whole grids of its share of the step's "
+                         "scalar fields, only shell tables cross the node (grids that fit one GPU)")
+    ap.add_argument("--no-alternative", action="store_true",
+                    help="several GPUs, slab decomposition: skip the extra timed leg with the field-parallel decomposition")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="diagnostic: time ONE rank's share of a G-rank slab decomposition on one GPU "
                          "(x-slab N/G, segmented x pass, exchanges skipped; the spectrum is not meaningful)")
@@ -148,6 +154,9 @@ class Workload:
         nx = self.nx
         maxc = max(NCOMP[q] for q in self.quantities)
         self.slab_particles = None
+        if isinstance(comm, device.FieldComm) and not (route == "ngp" and not unfused
+                                                        and all(K.fused_supported(N, device.QUANTITY[q]) for q in self.quantities)):
+            raise SystemExit("--decomposition fields: the field-parallel step is the fused NGP path (grid sizes the pencil kernel covers)")
         if route == "ngp":
             self.fused = (not unfused) and all(K.fused_supported(N, device.QUANTITY[q]) for q in self.quantities)
             if self.fused and self.pipe.chunked and nx < N:
@@ -167,6 +176,11 @@ class Workload:
                 self.acc_q = [self.pipe.new_accumulators() for _ in self.quantities]
             elif self.fused and self.pipe.chunked:
                 self.zimg = K.empty((maxc, K.zimage_elems(N, nx)), torch.complex64)
+            elif self.fused and isinstance(comm, device.FieldComm):
+                # field-parallel ranks: whole grids, one scalar field at a time (device.FieldComm)
+                self.my_units = comm.mine(self.quantities)
+                self.spec = K.empty((1, N // 2, N, nx), torch.complex64)
+                self.nyq = K.empty((1, N, nx), torch.complex64)
             elif self.fused:
                 self.spec = K.empty((maxc, N // 2, N, nx), torch.complex64)
                 self.nyq = K.empty((maxc, N, nx), torch.complex64)
@@ -194,6 +208,8 @@ class Workload:
         if self.route == "ngp":
             if getattr(self, "pipelined", False):
                 return "fused deposit+z pass (pencil buckets); quantities pipelined against each other's exchanges"
+            if isinstance(self.comm, self.dev.FieldComm):
+                return "fused deposit+z pass (pencil buckets), one scalar field per launch; fields dealt out over the ranks"
             return "fused deposit+z pass (pencil buckets)" if self.fused else "deposit -> grid -> z pass"
         if self.route == "nn":
             return "exact-NN resample (library lattice) with v, m formed in its epilogue -> z pass (p = v*m formed in the pass)"
@@ -226,6 +242,25 @@ class Workload:
                 tab = self.pipe.finish(*self.acc_q[i])
                 tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2
                 out[q] = tab
+            return out
+        if self.route == "ngp" and self.fused and isinstance(self.comm, dev.FieldComm):
+            # field-parallel: this rank's share of the step's scalar fields, whole grid each; the closing reduction of a
+            # quantity adds the shell sums of all ranks (a vector quantity's |F|^2 are summed over components anyway)
+            token = None
+            self.pipe.prepare()
+            for q in self.quantities:
+                self.acc_buf.zero_()
+                first = True
+                for (qq, c) in self.my_units:
+                    if qq != q:
+                        continue
+                    with K.binning_only():
+                        spec, nyq = K.deposit_fft_zy(self.pos, self.vel, self.rho, N, L, 0, N, dev.QUANTITY[q],
+                                                     spec=self.spec, nyq=self.nyq, reuse_sort=token, component=c)
+                    token = K.fused_token()
+                    self.pipe.accumulate_spectra(spec, nyq, self.psum, self.nsample, count=first)
+                    first = False
+                out[q] = self._table()
             return out
         if self.route == "ngp":
             token = None
@@ -407,7 +442,8 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / steps * 1e3
-    cells = float(N) ** 3 * nfields * world / G   # grid cells x scalar fields per step (whole job; emulation: one rank's share)
+    fw = getattr(comm, "field_world", 1)          # field-parallel ranks (device.FieldComm): G = 1, the FIELDS are dealt out
+    cells = float(N) ** 3 * nfields * world / (G * fw)   # grid cells x scalar fields per step (whole job; emulation: one rank's share)
 
     # ---- per-kernel durations (HIP events on the library's stream), untimed extra steps ----
     K.timing(True)
@@ -429,8 +465,11 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     # algorithmic HBM bytes of the main launches of ONE step, per kernel family (DESIGN.md "Kernels"): what the kernels
     # have to move -- rows (ky, kz) beyond the last shell edge are neither written by the y pass nor read by the x pass
     keep = wl_keep
-    step_bytes = {"fft_y": nfields * 8.0 * nx * N * NH * (1.0 + keep), "fft_x": nfields * 8.0 * nkz * N * N * keep}
-    if route == "ngp" and wl.fused:
+    nfl = len(wl.my_units) if fw > 1 else nfields     # scalar fields THIS rank transforms per step (field-parallel: its share)
+    step_bytes = {"fft_y": nfl * 8.0 * nx * N * NH * (1.0 + keep), "fft_x": nfl * 8.0 * nkz * N * N * keep}
+    if route == "ngp" and wl.fused and fw > 1:
+        step_bytes["fft_z"] = nfl * (8.0 * nx * N * (NH + 1) + 20.0 * Nps)
+    elif route == "ngp" and wl.fused:
         step_bytes["fft_z"] = sum(NCOMP[q] * 8.0 * nx * N * (NH + 1) + 20.0 * Nps for q in quantities)
     else:
         wread = 4.0 * nx * N * N if (route == "nn" and "momentum" in quantities) else 0.0
@@ -443,7 +482,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     dom = max(kms, key=lambda k: kms[k])
     ach = step_bytes[dom] / (kms[dom] * 1e-3) / 1e9
     fft_ms = sum(step_kernel_ms.get(k, 0.0) for k in ("fft_z", "fft_y", "fft_x"))
-    fft_bytes = step_bytes["fft_z"] + nfields * (8.0 * nx * N * (NH + 1) * (1.0 + keep) + 8.0 * (nkz * N + nky) * N * keep)
+    fft_bytes = step_bytes["fft_z"] + nfl * (8.0 * nx * N * (NH + 1) * (1.0 + keep) + 8.0 * (nkz * N + nky) * N * keep)
     grid_ms = step_kernel_ms.get("deposit", 0.0) + step_kernel_ms.get("algebra", 0.0) \
         + step_kernel_ms.get("nn_build", 0.0) + step_kernel_ms.get("nn_query", 0.0)
     traffic = None
@@ -465,7 +504,10 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
                    "grid": N, "particles": Np, "route": route, "quantities": list(quantities),
                    "scalar_fields_per_step": nfields, "path": wl.describe_path(),
                    "parallelism": ("x-slab x%d, one message per field and pair of ranks in %d kz chunks (unbinned rows left out, Nyquist rows inside it)"
-                                   % (world, nchunks)) if (G == world and world > 1) else "one GPU, no exchange" if G == world else ("EMULATED rank 0 of %d on one GPU, exchanges skipped (diagnostic)" % G)},
+                                   % (world, nchunks)) if (G == world and world > 1)
+                   else ("field-parallel: the step's %d scalar fields dealt out over %d ranks, whole %d^3 grid per GPU, only shell tables cross the node"
+                         % (nfields, fw, N)) if fw > 1
+                   else "one GPU, no exchange" if G == world else ("EMULATED rank 0 of %d on one GPU, exchanges skipped (diagnostic)" % G)},
         "data": data,
         "particles_per_s": Np / (grid_ms * 1e-3) if grid_ms > 0 else None,
         "gridding_note": ("bucket sort only: the LDS accumulation of the fused path lives in the fft_z launch"
@@ -493,7 +535,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     # (the oracle cannot follow at this size; these are the size-independent properties of SURVEY.md section 4, computed with
     # torch float64 as the calculator: oracle/gpu_checks.py.  What they exercise are the kernels that dominate the timed
     # region -- wide y pass, 512-thread pencils, 64-bit sort keys, row-cut packing -- which the small oracle sample cannot.)
-    if not args.no_full_check and G == world and not os.environ.get("VPS_BENCH_NOCHECK"):
+    if not args.no_full_check and (G == world or fw == world) and not os.environ.get("VPS_BENCH_NOCHECK"):
         from oracle import gpu_checks as chk
         counts = chk.shell_counts_exact(K.device, N, wl.pipe.k2, wl.pipe.thr)
         full = {"nsample_exact": bool(all(np.array_equal(t[:, 3], counts) for t in tabs.values())),
@@ -524,6 +566,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     # [rho v, rho], field algebra, the three velocity fields written to HBM -- timed by itself.  (In the fused path the
     # accumulation lives inside the z-pass launch and cannot be timed apart; the sort alone would flatter.)
     gridding = None
+    slab_tabs = tabs
     del wl, tabs
     K._work.clear()
     torch.cuda.empty_cache()
@@ -549,13 +592,47 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
         except Exception as e:      # (out of memory on a box with less HBM: keep the sort-only figure, say so)
             res["gridding_note"] += "; standalone deposit not timed: %s" % str(e)[:80]
             K.timing(False)
+    # ---- several GPUs, a grid that fits one of them: the same step with the FIELDS dealt out instead of the slabs ----
+    # (reported beside `value`, never as `value`: BASELINE's C4 is the slab decomposition.  xGMI is point-to-point: the slab
+    #  all-to-all moves the whole half spectrum of every field through the links, at two ranks through ONE link; dealing the
+    #  seven scalar fields out moves nbins numbers.  Its tables are checked against the slab run's, both at full size.)
+    fits_one_gpu = 20.0 * float(N) ** 3 < 0.75 * torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
+    if world > 1 and G == world and route == "ngp" and not args.unfused and not args.no_alternative and fits_one_gpu:
+        fcomm = device.FieldComm()
+        fwl = Workload(K, fcomm, N, L, route, quantities, flavour, dpos, dvel, drho)
+        if fwl.fused:
+            for _ in range(warmup):
+                ftabs = fwl.step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ftabs = fwl.step()
+            barrier()
+            dtf = time.perf_counter() - t0
+            t = torch.tensor([dtf], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtf = float(t.item())
+            eq, worst = compare_tables(ftabs, slab_tabs)
+            res["alternative"] = {
+                "decomposition": "fields", "ms_per_step": dtf / steps * 1e3, "value": float(N) ** 3 * nfields * steps / dtf,
+                "unit": "grid cells*components/s",
+                "parallelism": "the step's %d scalar fields dealt out over %d ranks (rank r: fields r, r + %d, ...), whole %d^3 grid "
+                               "per GPU, particles replicated as in the slab run; only the shell tables cross the node"
+                               % (nfields, world, world, N),
+                "vs_slab_tables": {"nsample_equal": eq, "psum_max_rel": worst},
+                "note": "python bench.py --gpus N --decomposition fields makes this the reported decomposition"}
+            if rank == 0 and not os.environ.get("VPS_BENCH_NOCHECK"):
+                assert eq and worst <= PSUM_RTOL, "field-parallel and slab tables differ: %s %.3g" % (eq, worst)
+        del fwl
+        K._work.clear()
+        torch.cuda.empty_cache()
     # release the big buffers before the sample / the next config
     del dpos, dvel, drho
     K._work.clear()
     torch.cuda.empty_cache()
 
     # ---- the same step function on a small sample, against the oracle ----
-    if want_parity and G == world:
+    if want_parity and (G == world or fw == world):
         Ns, Nps_ = sample_size(route, N, Np)
         while Ns % (2 * world):
             Ns *= 2
@@ -655,7 +732,9 @@ def main(argv=None):
     from vpower import device, synth
     K = device.default_kernels(local)
     comm = device.SlabComm()
-    if os.environ.get("VPS_BENCH_TRANSPORT") == "library" and world > 1 and backend == "nccl":
+    if args.decomposition == "fields" and world > 1:
+        comm = device.FieldComm()
+    elif os.environ.get("VPS_BENCH_TRANSPORT") == "library" and world > 1 and backend == "nccl":
         # the exchange inside libvps_hip.so (vps_spectrum_zimages: RCCL send / recv groups on the library's own stream)
         # instead of torch.distributed.all_to_all_single; torch only moves the 128-byte id and times the run
         comm = device.LibraryComm(K)
@@ -677,7 +756,7 @@ def main(argv=None):
         raise SystemExit("unknown config %s" % cfg)
     single = world == 1 and comm.world == 1
     res = run_config(args, cfg, K, comm, world, rank, backend, args.steps, args.warmup, args.profile_steps,
-                     want_parity=not args.no_parity and comm.world == world,
+                     want_parity=not args.no_parity and (comm.world == world or getattr(comm, "field_world", 1) == world),
                      want_cpu=single and not args.no_cpu_baseline)
     out = {
         "metric": baseline_json()["metric"],

@@ -1348,10 +1348,17 @@ static int deposit_fft_impl(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, c
   }
   const double lc = Lbox / (double)N;
   const int bug = (quantity == VPS_MOMENTUM) && (flags & VPS_FLAG_REFERENCE_MOMENTUM_BUG);
-  const int chan[3] = {0, bug ? 0 : 1, bug ? 0 : 2};
+  int chan[3] = {0, bug ? 0 : 1, bug ? 0 : 2};
+  int ncomp = 3;
+  const int only = (flags & VPS_FLAG_COMPONENT_MASK) >> 4;   // 1..3: that component alone (VPS_FLAG_COMPONENT)
+  if (only) {
+    if (quantity == VPS_ENERGY) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_fft_zy: VPS_FLAG_COMPONENT with the (scalar) energy field");
+    chan[0] = chan[only - 1];
+    ncomp = 1;
+  }
   // (the sort's rank array -- one word per particle, dead once the records are in place -- is the kernel's per-record scratch)
   return vps_fft_pencil_zy(ctx, N, nx, reinterpret_cast<const unsigned*>(work + l.records),
-                           reinterpret_cast<const unsigned*>(work + l.start), reinterpret_cast<float*>(work + l.ranks), 3, chan,
+                           reinterpret_cast<const unsigned*>(work + l.start), reinterpret_cast<float*>(work + l.ranks), ncomp, chan,
                            quantity == VPS_MOMENTUM ? 0 : 1, quantity == VPS_ENERGY ? 1 : 0, (float)(lc * lc * lc),
                            spec_dev, nyq_dev, zimg_dev ? zimg_dev : (void*)(work + l.total));
 }

@@ -296,11 +296,18 @@ class HipKernels:
     def fused_supported(self, N, quantity):
         return bool(self.lib.vps_deposit_fft_zy_supported(self.ctx, int(N), int(quantity)))
 
-    def deposit_fft_zy(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, spec=None, nyq=None, reuse_sort=None):
+    def deposit_fft_zy(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, spec=None, nyq=None, reuse_sort=None,
+                       component=None):
         """Fused deposit + field algebra + z/y passes:
-        -> spec [ncomp, N/2, N, nx], nyq [ncomp, N, nx] (complex64); ncomp = 1 for ENERGY, else 3."""
+        -> spec [ncomp, N/2, N, nx], nyq [ncomp, N, nx] (complex64); ncomp = 1 for ENERGY, else 3.
+        component = 0..2: that component of a velocity / momentum field alone (ncomp = 1; VPS_FLAG_COMPONENT)."""
         self._stream()
         ncomp = 1 if quantity == ENERGY else 3
+        if component is not None:
+            if quantity == ENERGY or not 0 <= int(component) <= 2:
+                raise Exception("component = 0..2 of a velocity or momentum field")
+            flags |= (int(component) + 1) << 4
+            ncomp = 1
         if spec is None:
             spec = self.empty((ncomp, N // 2, N, nx), torch.complex64)
         if nyq is None:
@@ -465,12 +472,18 @@ class HipKernels:
             self._chk(n)
         return n
 
-    def deposit_fft_z(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, zimg=None, reuse_sort=None, slab_particles=None):
+    def deposit_fft_z(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, zimg=None, reuse_sort=None, slab_particles=None,
+                      component=None):
         """Fused deposit + field algebra + z pass -> z images [ncomp, zimage_elems] (ncomp = 1 for ENERGY, else 3).
         slab_particles: a bound on the particles inside the slab (count_in_slab): the sort workspace is then sized for it,
-        not for all of a replicated particle set."""
+        not for all of a replicated particle set.  component: as in deposit_fft_zy."""
         self._stream()
         ncomp = 1 if quantity == ENERGY else 3
+        if component is not None:
+            if quantity == ENERGY or not 0 <= int(component) <= 2:
+                raise Exception("component = 0..2 of a velocity or momentum field")
+            flags |= (int(component) + 1) << 4
+            ncomp = 1
         if zimg is None:
             zimg = self.empty((ncomp, self.zimage_elems(N, nx)), torch.complex64)
         if slab_particles is None:
@@ -709,6 +722,41 @@ class SlabComm:
             t.copy_(h)
             return t
         self.dist.all_reduce(t, group=self.group)
+        return t
+
+
+class FieldComm(SlabComm):
+    """Field-parallel ranks: every rank holds WHOLE grids and transforms a share of the scalar fields of a step (the three
+    components of a vector quantity, the energy field, several quantities); nothing but the shell tables crosses the node.
+    For grids that fit one GPU's 288 GB this is the decomposition that suits point-to-point xGMI: the slab decomposition sends
+    the whole half spectrum through the links once per field (at two ranks through ONE link), this one sends nbins numbers.
+    To the pipeline the rank is a one-rank slab (world = 1: nx = N, no exchange); `field_rank` / `field_world` say which
+    fields are this rank's (`mine`), and the closing reductions ADD the shell sums of all ranks and take the shell counts from
+    whichever ranks counted (MAX: they depend on the mode lattice alone, so every rank that counted holds the same numbers)."""
+
+    def __init__(self, group=None, enabled=None):
+        super().__init__(group=group, enabled=enabled)
+        self.field_rank, self.field_world = self.rank, self.world
+        self.rank, self.world, self.force = 0, 1, False
+
+    @staticmethod
+    def units(quantities):
+        """The scalar fields of a step, in dealing order: (quantity, component) -- component None for the energy field."""
+        return [(q, c) for q in quantities for c in ((None,) if q == "energy" else (0, 1, 2))]
+
+    def mine(self, quantities):
+        return self.units(quantities)[self.field_rank::self.field_world]
+
+    def all_reduce_sum(self, t):
+        if self.field_world == 1:
+            return t
+        op = self.dist.ReduceOp.SUM if t.is_floating_point() else self.dist.ReduceOp.MAX
+        if t.is_cuda and self.backend != "nccl":
+            h = t.cpu()
+            self.dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+            return t
+        self.dist.all_reduce(t, op=op, group=self.group)
         return t
 
 

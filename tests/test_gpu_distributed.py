@@ -248,3 +248,53 @@ def test_bench_quantity_pipelined_step_on_shared_gpu(tmp_path, world, N, chunks,
             assert np.array_equal(tab[:, 3], ref[:, 3])
             assert np.allclose(tab[:, 2], ref[:, 2], rtol=2e-5, atol=0)
             assert np.allclose(tab[:, 1], ref[:, 1], rtol=2e-5, atol=0)
+
+
+def _bench_fields_worker(rank, world, port, N, Np, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "large-velocity-power-spectrum_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from vpower import device, synth
+        K = device.default_kernels(0)
+        pos, vel, mass, dens = synth.particles(43, Np, 1.0)
+        comm = device.FieldComm()
+        assert (comm.world, comm.rank, comm.field_world, comm.field_rank) == (1, 0, world, rank)
+        wl = bench.Workload(K, comm, N, 1.0, "ngp", ("velocity", "momentum", "energy"), "library",
+                            K.to_device(pos), K.to_device(vel), K.to_device(dens))
+        assert wl.fused and wl.nx == N and not wl.pipe.chunked
+        assert wl.my_units == device.FieldComm.units(("velocity", "momentum", "energy"))[rank::world]
+        tabs = wl.step()
+        tabs2 = wl.step()
+        for q in tabs:
+            assert np.array_equal(tabs[q][:, 3], tabs2[q][:, 3]) and np.allclose(tabs[q][:, 2], tabs2[q][:, 2], rtol=1e-6)
+        np.save(os.path.join(out_dir, f"ftabs_{rank}.npy"), np.stack([tabs[q] for q in ("velocity", "momentum", "energy")]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N", [(2, 128), (4, 128), (3, 64)])
+def test_bench_field_parallel_step_on_shared_gpu(tmp_path, world, N):
+    """`bench.py --decomposition fields` (and the `alternative` leg of the slab run): the seven scalar fields of the C4 step dealt
+    out over 2 / 3 / 4 gloo ranks sharing the one GPU, whole grids, one VPS_FLAG_COMPONENT launch per field; shell sums added and
+    shell counts MAX-reduced over the ranks (device.FieldComm).  Every rank's three tables against the oracle."""
+    import torch.multiprocessing as mp
+    from vpower import synth
+    Np = 300000
+    mp.spawn(_bench_fields_worker, args=(world, _free_port(), N, Np, str(tmp_path)), nprocs=world, join=True)
+    pos, vel, mass, dens = synth.particles(43, Np, 1.0)
+    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
+    v, m = orc.vm_from_vec_grid(orc.deposit_to_grid_fast(vec, pos, N, 1.0), 1.0 / N, zero_empty=True)
+    refs = [orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, 1.0 / N, q) for q in ("velocity", "momentum", "energy")]
+    for r in range(world):
+        tabs = np.load(tmp_path / f"ftabs_{r}.npy")
+        for tab, ref in zip(tabs, refs):
+            assert np.array_equal(tab[:, 3], ref[:, 3])
+            assert np.allclose(tab[:, 2], ref[:, 2], rtol=2e-5, atol=0)
+            assert np.allclose(tab[:, 1], ref[:, 1], rtol=2e-5, atol=0)
