@@ -599,9 +599,18 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     fits_one_gpu = 20.0 * float(N) ** 3 < 0.75 * torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
     if world > 1 and G == world and route == "ngp" and not args.unfused and not args.no_alternative and fits_one_gpu:
         fcomm = device.FieldComm()
-        fwl = Workload(K, fcomm, N, L, route, quantities, flavour, dpos, dvel, drho)
-        if fwl.fused:
-            for _ in range(warmup):
+        fwl, ok_local = None, 1
+        try:        # (buffers of ~150 GB at 2048^3: a rank that cannot allocate them says so, and every rank skips the leg)
+            fwl = Workload(K, fcomm, N, L, route, quantities, flavour, dpos, dvel, drho)
+            fwl.K.workspace("fused", fwl.K.lib.vps_deposit_fft_zy_workspace_bytes(dpos.shape[0], N, N))
+        except torch.OutOfMemoryError:
+            ok_local = 0
+        okt = torch.tensor([ok_local], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:
+            res["alternative"] = {"decomposition": "fields", "skipped": "a rank could not allocate the whole-grid buffers"}
+        elif fwl.fused:
+            for _ in range(max(warmup, 1)):
                 ftabs = fwl.step()
             barrier()
             t0 = time.perf_counter()
@@ -634,7 +643,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     # ---- the same step function on a small sample, against the oracle ----
     if want_parity and (G == world or fw == world):
         Ns, Nps_ = sample_size(route, N, Np)
-        while Ns % (2 * world):
+        while fw == 1 and Ns % (2 * world):      # (slabs: N/2 divisible by the ranks; field-parallel ranks hold whole grids)
             Ns *= 2
         pos, vel, mass, dens = synth.particles(synth.BASE_SEED + 100 + off, Nps_, L, lognormal)
         swl = Workload(K, comm, Ns, L, route, quantities, flavour, K.to_device(pos), K.to_device(vel),
