@@ -179,8 +179,9 @@ class Workload:
             elif self.fused and isinstance(comm, device.FieldComm):
                 # field-parallel ranks: whole grids, one scalar field at a time (device.FieldComm)
                 self.my_units = comm.mine(self.quantities)
-                self.spec = K.empty((1, N // 2, N, nx), torch.complex64)
-                self.nyq = K.empty((1, N, nx), torch.complex64)
+                mc = max([sum(1 for u in self.my_units if u[0] == q) for q in self.quantities] + [1])
+                self.spec = K.empty((mc, N // 2, N, nx), torch.complex64)
+                self.nyq = K.empty((mc, N, nx), torch.complex64)
             elif self.fused:
                 self.spec = K.empty((maxc, N // 2, N, nx), torch.complex64)
                 self.nyq = K.empty((maxc, N, nx), torch.complex64)
@@ -250,16 +251,15 @@ class Workload:
             self.pipe.prepare()
             for q in self.quantities:
                 self.acc_buf.zero_()
-                first = True
-                for (qq, c) in self.my_units:
-                    if qq != q:
-                        continue
+                comps = [c for (qq, c) in self.my_units if qq == q]
+                if comps:       # this rank's components of q in ONE launch (None: the energy field)
+                    nc = len(comps)
                     with K.binning_only():
                         spec, nyq = K.deposit_fft_zy(self.pos, self.vel, self.rho, N, L, 0, N, dev.QUANTITY[q],
-                                                     spec=self.spec, nyq=self.nyq, reuse_sort=token, component=c)
+                                                     spec=self.spec[:nc], nyq=self.nyq[:nc], reuse_sort=token,
+                                                     component=None if comps[0] is None else comps)
                     token = K.fused_token()
-                    self.pipe.accumulate_spectra(spec, nyq, self.psum, self.nsample, count=first)
-                    first = False
+                    self.pipe.accumulate_spectra(spec, nyq, self.psum, self.nsample)
                 out[q] = self._table()
             return out
         if self.route == "ngp":
@@ -625,9 +625,9 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
             res["alternative"] = {
                 "decomposition": "fields", "ms_per_step": dtf / steps * 1e3, "value": float(N) ** 3 * nfields * steps / dtf,
                 "unit": "grid cells*components/s",
-                "parallelism": "the step's %d scalar fields dealt out over %d ranks (rank r: fields r, r + %d, ...), whole %d^3 grid "
-                               "per GPU, particles replicated as in the slab run; only the shell tables cross the node"
-                               % (nfields, world, world, N),
+                "parallelism": "the step's %d scalar fields dealt out over %d ranks in contiguous blocks (a rank's components of a quantity "
+                               "in one launch), whole %d^3 grid per GPU, particles replicated as in the slab run; only the shell tables "
+                               "cross the node" % (nfields, world, N),
                 "vs_slab_tables": {"nsample_equal": eq, "psum_max_rel": worst},
                 "note": "python bench.py --gpus N --decomposition fields makes this the reported decomposition"}
             if rank == 0 and not os.environ.get("VPS_BENCH_NOCHECK"):

@@ -51,11 +51,13 @@ enum vps_quantity { VPS_VELOCITY = 0, VPS_MOMENTUM = 1, VPS_ENERGY = 2,
                                               previous call with the SAME particles, N, Lbox, x0, nx -- skip the sort
                                               (several quantities of one snapshot) */
 
-#define VPS_FLAG_COMPONENT(c) (((c) + 1) << 4) /* vps_deposit_fft_zy / vps_deposit_fft_z[_slab], velocity or momentum: produce ONLY
-                                              component c (0..2) -- one scalar image / half spectrum at the start of the output,
-                                              component c of the three-component call (up to the order of the LDS float adds).  For hosts that deal
+#define VPS_FLAG_COMPONENTS(mask) (((mask) & 7) << 4) /* vps_deposit_fft_zy / vps_deposit_fft_z[_slab], velocity or momentum: produce
+                                              ONLY the components in `mask` (bit c = component c; 0 = all three), in ascending
+                                              order at the start of the output -- the scalar images / half spectra of the
+                                              three-component call (up to the order of the LDS float adds).  For hosts that deal
                                               the scalar fields of a step out over several GPUs (whole grids, no exchange). */
-#define VPS_FLAG_COMPONENT_MASK 0x30
+#define VPS_FLAG_COMPONENT(c) VPS_FLAG_COMPONENTS(1 << (c))
+#define VPS_FLAG_COMPONENT_MASK 0x70
 
 /* ---- lifecycle ---------------------------------------------------------- */
 int vps_create(vps_ctx** out, int device_id);

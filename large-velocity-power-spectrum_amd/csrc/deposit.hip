@@ -1350,11 +1350,13 @@ static int deposit_fft_impl(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, c
   const int bug = (quantity == VPS_MOMENTUM) && (flags & VPS_FLAG_REFERENCE_MOMENTUM_BUG);
   int chan[3] = {0, bug ? 0 : 1, bug ? 0 : 2};
   int ncomp = 3;
-  const int only = (flags & VPS_FLAG_COMPONENT_MASK) >> 4;   // 1..3: that component alone (VPS_FLAG_COMPONENT)
+  const int only = (flags & VPS_FLAG_COMPONENT_MASK) >> 4;   // bit c: component c is wanted (VPS_FLAG_COMPONENTS); 0: all
   if (only) {
-    if (quantity == VPS_ENERGY) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_fft_zy: VPS_FLAG_COMPONENT with the (scalar) energy field");
-    chan[0] = chan[only - 1];
-    ncomp = 1;
+    if (quantity == VPS_ENERGY) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_fft_zy: VPS_FLAG_COMPONENTS with the (scalar) energy field");
+    const int all[3] = {chan[0], chan[1], chan[2]};
+    ncomp = 0;
+    for (int c = 0; c < 3; ++c)
+      if (only & (1 << c)) chan[ncomp++] = all[c];
   }
   // (the sort's rank array -- one word per particle, dead once the records are in place -- is the kernel's per-record scratch)
   return vps_fft_pencil_zy(ctx, N, nx, reinterpret_cast<const unsigned*>(work + l.records),

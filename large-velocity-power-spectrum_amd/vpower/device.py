@@ -300,14 +300,14 @@ class HipKernels:
                        component=None):
         """Fused deposit + field algebra + z/y passes:
         -> spec [ncomp, N/2, N, nx], nyq [ncomp, N, nx] (complex64); ncomp = 1 for ENERGY, else 3.
-        component = 0..2: that component of a velocity / momentum field alone (ncomp = 1; VPS_FLAG_COMPONENT)."""
+        component = 0..2, or a collection of them: only those components of a velocity / momentum field, in ascending order
+        (ncomp = their number; VPS_FLAG_COMPONENTS)."""
         self._stream()
         ncomp = 1 if quantity == ENERGY else 3
         if component is not None:
-            if quantity == ENERGY or not 0 <= int(component) <= 2:
-                raise Exception("component = 0..2 of a velocity or momentum field")
-            flags |= (int(component) + 1) << 4
-            ncomp = 1
+            mask = self._component_mask(quantity, component)
+            flags |= mask << 4
+            ncomp = bin(mask).count("1")
         if spec is None:
             spec = self.empty((ncomp, N // 2, N, nx), torch.complex64)
         if nyq is None:
@@ -319,6 +319,17 @@ class HipKernels:
                                               pos.shape[0], N, float(Lbox), x0, nx, quantity, flags,
                                               self._ptr(spec), self._ptr(nyq), self._ptr(work)))
         return spec, nyq
+
+    @staticmethod
+    def _component_mask(quantity, component):
+        """component: 0..2 or a collection of them -> the bit mask of VPS_FLAG_COMPONENTS."""
+        comps = (component,) if isinstance(component, (int, np.integer)) else tuple(component)
+        if quantity == ENERGY or not comps or any(not 0 <= int(c) <= 2 for c in comps) or len(set(comps)) != len(comps):
+            raise Exception("component(s) = distinct values 0..2 of a velocity or momentum field")
+        mask = 0
+        for c in comps:
+            mask |= 1 << int(c)
+        return mask
 
     def _reuse_flag(self, reuse_sort, pos, vel, rho, N, Lbox, x0, nx, work, cap=None):
         """FLAG_REUSE_SORT if `reuse_sort` (a token returned by an earlier fused call) proves that the bucketed records
@@ -480,10 +491,9 @@ class HipKernels:
         self._stream()
         ncomp = 1 if quantity == ENERGY else 3
         if component is not None:
-            if quantity == ENERGY or not 0 <= int(component) <= 2:
-                raise Exception("component = 0..2 of a velocity or momentum field")
-            flags |= (int(component) + 1) << 4
-            ncomp = 1
+            mask = self._component_mask(quantity, component)
+            flags |= mask << 4
+            ncomp = bin(mask).count("1")
         if zimg is None:
             zimg = self.empty((ncomp, self.zimage_elems(N, nx)), torch.complex64)
         if slab_particles is None:
@@ -745,7 +755,13 @@ class FieldComm(SlabComm):
         return [(q, c) for q in quantities for c in ((None,) if q == "energy" else (0, 1, 2))]
 
     def mine(self, quantities):
-        return self.units(quantities)[self.field_rank::self.field_world]
+        """This rank's fields: CONTIGUOUS blocks of the dealing order (the first n mod W ranks take one more), so that a rank's
+        fields mostly belong to one quantity and go through one multi-component launch (shared rho round, one shell search)."""
+        u = self.units(quantities)
+        W, r = self.field_world, self.field_rank
+        base, extra = divmod(len(u), W)
+        lo = r * base + min(r, extra)
+        return u[lo: lo + base + (1 if r < extra else 0)]
 
     def all_reduce_sum(self, t):
         if self.field_world == 1:

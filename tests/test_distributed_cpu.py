@@ -166,7 +166,9 @@ def _fields_worker(rank, world, port, N, L, seed, out_dir):
         units = device.FieldComm.units(quantities)
         assert units == [("velocity", 0), ("velocity", 1), ("velocity", 2), ("energy", None)]
         mine = comm.mine(quantities)
-        assert mine == units[rank::world]
+        base, extra = divmod(len(units), world)          # contiguous blocks, the first `extra` ranks one field more
+        lo = rank * base + min(rank, extra)
+        assert mine == units[lo: lo + base + (1 if rank < extra else 0)]
         rng = np.random.default_rng(seed)
         fields = {("velocity", c): rng.standard_normal((N, N, N)).astype(np.float32) for c in range(3)}
         fields[("energy", None)] = rng.standard_normal((N, N, N)).astype(np.float32)

@@ -269,7 +269,10 @@ def _bench_fields_worker(rank, world, port, N, Np, out_dir):
         wl = bench.Workload(K, comm, N, 1.0, "ngp", ("velocity", "momentum", "energy"), "library",
                             K.to_device(pos), K.to_device(vel), K.to_device(dens))
         assert wl.fused and wl.nx == N and not wl.pipe.chunked
-        assert wl.my_units == device.FieldComm.units(("velocity", "momentum", "energy"))[rank::world]
+        units = device.FieldComm.units(("velocity", "momentum", "energy"))
+        base, extra = divmod(len(units), world)
+        lo = rank * base + min(rank, extra)
+        assert wl.my_units == units[lo: lo + base + (1 if rank < extra else 0)]
         tabs = wl.step()
         tabs2 = wl.step()
         for q in tabs:

@@ -812,7 +812,12 @@ def test_single_component_launch_equals_the_vector_launch(K, N, quantity, flags)
     for c in range(3):
         z1 = K.deposit_fft_z(dpos, dvel, drho, N, 1.0, 0, N, q, flags=flags, component=c)
         assert z1.shape[0] == 1 and same(z1[0], z3[c])
+    # two components in one launch: in ascending order at the start of the output
+    s2, n2 = K.deposit_fft_zy(dpos, dvel, drho, N, 1.0, 0, N, q, flags=flags, component=(2, 0))
+    assert s2.shape[0] == 2 and same(s2[0], spec3[0]) and same(s2[1], spec3[2]) and same(n2[1], nyq3[2])
     with pytest.raises(Exception):
         K.deposit_fft_zy(dpos, dvel, drho, N, 1.0, 0, N, device.ENERGY, component=0)
+    with pytest.raises(Exception):
+        K.deposit_fft_zy(dpos, dvel, drho, N, 1.0, 0, N, q, component=(1, 1))
     with pytest.raises(Exception):     # the library refuses the flag for energy as well
         K.deposit_fft_zy(dpos, dvel, drho, N, 1.0, 0, N, device.ENERGY, flags=(1 << 4))

@@ -1,5 +1,5 @@
 """One rank's share of the field-parallel decomposition at C4, timed on one GPU: python tools/time_fields.py W r [W r ...]
-(rank r of W: scalar fields r, r + W, ... of [v0 v1 v2 p0 p1 p2 e]; the closing reductions are local)."""
+(rank r of W: its contiguous block of [v0 v1 v2 p0 p1 p2 e]; the closing reductions are local)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "large-velocity-power-spectrum_amd"))
