@@ -62,12 +62,13 @@ def parse_args(argv=None):
                     help="skip the full-size checks of the timed step's tables (exact shell counts, Parseval over all modes)")
     ap.add_argument("--unfused", action="store_true", help="NGP route: separate deposit and z-pass kernels (grid through HBM)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the roofline")
-    ap.add_argument("--decomposition", choices=("slab", "fields"), default="slab",
-                    help="several GPUs: 'slab' = 1-D x-slabs with one all-to-all per field (BASELINE's C4 / C5 configuration, the "
-                         "default and the reported value); 'fields' = every rank transforms whole grids of its share of the step's "
-                         "scalar fields, only shell tables cross the node (grids that fit one GPU)")
+    ap.add_argument("--decomposition", choices=("auto", "slab", "fields"), default="auto",
+                    help="several GPUs: 'slab' = 1-D x-slabs with one all-to-all per field (any grid; the only choice beyond one "
+                         "GPU's memory: C5); 'fields' = every rank transforms whole grids of its share of the step's scalar fields, "
+                         "only shell tables cross the node (grids that fit one GPU); 'auto' = fields where possible, else slab.  "
+                         "The decomposition that is not chosen is timed as well and reported under `alternative`")
     ap.add_argument("--no-alternative", action="store_true",
-                    help="several GPUs, slab decomposition: skip the extra timed leg with the field-parallel decomposition")
+                    help="several GPUs: skip the extra timed leg with the other decomposition")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="diagnostic: time ONE rank's share of a G-rank slab decomposition on one GPU "
                          "(x-slab N/G, segmented x pass, exchanges skipped; the spectrum is not meaningful)")
@@ -313,6 +314,16 @@ class Workload:
         return out
 
 
+def fields_possible(K, N, route, quantities, unfused=False):
+    """Can every rank hold WHOLE grids (the field-parallel decomposition, device.FieldComm)?  The fused NGP path at a size whose
+    buffers (spectrum of up to three components, z images, sort workspace: ~26 N^3 bytes) fit three quarters of the GPU."""
+    import torch
+    from vpower import device
+    if route != "ngp" or unfused or not all(K.fused_supported(N, device.QUANTITY[q]) for q in quantities):
+        return False
+    return 26.0 * float(N) ** 3 < 0.78 * torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
+
+
 def oracle_tables(route, quantities, flavour, N, L, pos, vel, dens):
     """The CPU oracle (oracle/vps_oracle.py: numpy restatement of the reference) on the same
     particles -> ({quantity: table}, {stage: seconds})."""
@@ -479,6 +490,8 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
         step_bytes["nn_query"] = Np * (12.0 + 4 * C_) + 4.0 * C_ * nx * N * N
     launches_per_step = {k: max(len(v) // nst, 1) for k, v in main.items() if len(v)}
     kms = {k: float(np.sum(v)) / nst for k, v in main.items() if len(v)}        # ms per step in main launches
+    if not kms:      # (a field-parallel rank beyond the last field: it only takes part in the reductions; never rank 0)
+        kms, launches_per_step, step_bytes = {"fft_y": 1e-9}, {"fft_y": 1}, dict(step_bytes, fft_y=0.0)
     dom = max(kms, key=lambda k: kms[k])
     ach = step_bytes[dom] / (kms[dom] * 1e-3) / 1e9
     fft_ms = sum(step_kernel_ms.get(k, 0.0) for k in ("fft_z", "fft_y", "fft_x"))
@@ -500,7 +513,11 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
         "ms_per_step": ms_per_step,
         "value": cells * steps / dt,
         "config": {"workload": "%s: %s" % (cfg, cfg_text),
-                   "deviation": rehearsal or (("strong-scaled over %d GPU(s) of one node" % world) if cfg in ("C4", "C5") and world != 8 else None),
+                   "deviation": rehearsal or "; ".join(x for x in (
+                       ("strong-scaled over %d GPU(s) of one node" % world) if cfg in ("C4", "C5") and world != 8 else None,
+                       ("field-parallel decomposition instead of the slab all-to-all the config names: the grid fits one GPU's HBM, so "
+                        "every rank transforms whole grids and nothing but shell tables crosses xGMI; the slab run of the same step "
+                        "is timed under `alternative` (--decomposition slab makes it the reported one)") if fw > 1 else None) if x) or None,
                    "grid": N, "particles": Np, "route": route, "quantities": list(quantities),
                    "scalar_fields_per_step": nfields, "path": wl.describe_path(),
                    "parallelism": ("x-slab x%d, one message per field and pair of ranks in %d kz chunks (unbinned rows left out, Nyquist rows inside it)"
@@ -566,7 +583,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     # [rho v, rho], field algebra, the three velocity fields written to HBM -- timed by itself.  (In the fused path the
     # accumulation lives inside the z-pass launch and cannot be timed apart; the sort alone would flatter.)
     gridding = None
-    slab_tabs = tabs
+    own_tabs = tabs
     del wl, tabs
     K._work.clear()
     torch.cuda.empty_cache()
@@ -592,47 +609,54 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
         except Exception as e:      # (out of memory on a box with less HBM: keep the sort-only figure, say so)
             res["gridding_note"] += "; standalone deposit not timed: %s" % str(e)[:80]
             K.timing(False)
-    # ---- several GPUs, a grid that fits one of them: the same step with the FIELDS dealt out instead of the slabs ----
-    # (reported beside `value`, never as `value`: BASELINE's C4 is the slab decomposition.  xGMI is point-to-point: the slab
-    #  all-to-all moves the whole half spectrum of every field through the links, at two ranks through ONE link; dealing the
-    #  seven scalar fields out moves nbins numbers.  Its tables are checked against the slab run's, both at full size.)
-    fits_one_gpu = 20.0 * float(N) ** 3 < 0.75 * torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
-    if world > 1 and G == world and route == "ngp" and not args.unfused and not args.no_alternative and fits_one_gpu:
-        fcomm = device.FieldComm()
-        fwl, ok_local = None, 1
-        try:        # (buffers of ~150 GB at 2048^3: a rank that cannot allocate them says so, and every rank skips the leg)
-            fwl = Workload(K, fcomm, N, L, route, quantities, flavour, dpos, dvel, drho)
-            fwl.K.workspace("fused", fwl.K.lib.vps_deposit_fft_zy_workspace_bytes(dpos.shape[0], N, N))
+    # ---- several GPUs, a grid that fits one of them: the same step under the OTHER decomposition, reported beside `value` ----
+    # (xGMI is point-to-point: the slab all-to-all moves the whole half spectrum of every field through the links, at two ranks
+    #  through ONE link; dealing the seven scalar fields out moves nbins numbers.  Whichever of the two is not the run's own
+    #  decomposition is timed here on the same particles, and its tables are checked against the run's own, both at full size.)
+    other = "slab" if fw > 1 else "fields"
+    can_other = (world > 1 and (G == world or fw == world) and not args.no_alternative
+                 and fields_possible(K, N, route, quantities, args.unfused)
+                 and (other == "fields" or (N % world == 0 and (N // 2) % world == 0)))
+    if can_other:
+        ocomm = device.FieldComm() if other == "fields" else device.SlabComm()
+        owl, ok_local = None, 1
+        try:        # (whole-grid buffers are ~150-220 GB at 2048^3: a rank that cannot allocate them says so, and every rank skips the leg)
+            owl = Workload(K, ocomm, N, L, route, quantities, flavour, dpos, dvel, drho)
+            if other == "fields":
+                K.workspace("fused", K.lib.vps_deposit_fft_zy_workspace_bytes(dpos.shape[0], N, N))
         except torch.OutOfMemoryError:
             ok_local = 0
         okt = torch.tensor([ok_local], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if int(okt.item()) == 0:
-            res["alternative"] = {"decomposition": "fields", "skipped": "a rank could not allocate the whole-grid buffers"}
-        elif fwl.fused:
+            res["alternative"] = {"decomposition": other, "skipped": "a rank could not allocate its buffers"}
+        else:
             for _ in range(max(warmup, 1)):
-                ftabs = fwl.step()
+                otabs = owl.step()
             barrier()
             t0 = time.perf_counter()
             for _ in range(steps):
-                ftabs = fwl.step()
+                otabs = owl.step()
             barrier()
-            dtf = time.perf_counter() - t0
-            t = torch.tensor([dtf], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dto = time.perf_counter() - t0
+            t = torch.tensor([dto], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtf = float(t.item())
-            eq, worst = compare_tables(ftabs, slab_tabs)
+            dto = float(t.item())
+            eq, worst = compare_tables(otabs, own_tabs)
             res["alternative"] = {
-                "decomposition": "fields", "ms_per_step": dtf / steps * 1e3, "value": float(N) ** 3 * nfields * steps / dtf,
+                "decomposition": other, "ms_per_step": dto / steps * 1e3, "value": float(N) ** 3 * nfields * steps / dto,
                 "unit": "grid cells*components/s",
-                "parallelism": "the step's %d scalar fields dealt out over %d ranks in contiguous blocks (a rank's components of a quantity "
-                               "in one launch), whole %d^3 grid per GPU, particles replicated as in the slab run; only the shell tables "
-                               "cross the node" % (nfields, world, N),
-                "vs_slab_tables": {"nsample_equal": eq, "psum_max_rel": worst},
-                "note": "python bench.py --gpus N --decomposition fields makes this the reported decomposition"}
+                "parallelism": ("the step's %d scalar fields dealt out over %d ranks in contiguous blocks (a rank's components of a quantity "
+                                "in one launch), whole %d^3 grid per GPU, particles replicated; only the shell tables cross the node"
+                                % (nfields, world, N)) if other == "fields" else
+                               ("x-slab x%d, one message per field and pair of ranks in %d kz chunks (unbinned rows left out), %s"
+                                % (world, owl.pipe.nchunks, owl.describe_path())),
+                "vs_own_tables": {"nsample_equal": eq, "psum_max_rel": worst},
+                "note": "python bench.py --gpus N --decomposition %s makes this the reported decomposition" % other}
             if rank == 0 and not os.environ.get("VPS_BENCH_NOCHECK"):
                 assert eq and worst <= PSUM_RTOL, "field-parallel and slab tables differ: %s %.3g" % (eq, worst)
-        del fwl
+            del otabs
+        del owl
         K._work.clear()
         torch.cuda.empty_cache()
     # release the big buffers before the sample / the next config
@@ -741,7 +765,14 @@ def main(argv=None):
     from vpower import device, synth
     K = device.default_kernels(local)
     comm = device.SlabComm()
-    if args.decomposition == "fields" and world > 1:
+    decomposition = args.decomposition
+    if decomposition == "auto":
+        # point-to-point xGMI: whole grids per GPU and no exchange wherever 288 GB allow it
+        N_ = int(os.environ.get("VPS_BENCH_GRID", synth.CONFIGS[args.config][0])) if args.config in synth.CONFIGS else 0
+        decomposition = "fields" if (world > 1 and args.config in synth.CONFIGS
+                                     and fields_possible(K, N_, synth.WORKLOADS[args.config][0], synth.WORKLOADS[args.config][1],
+                                                         args.unfused)) else "slab"
+    if decomposition == "fields" and world > 1:
         comm = device.FieldComm()
     elif os.environ.get("VPS_BENCH_TRANSPORT") == "library" and world > 1 and backend == "nccl":
         # the exchange inside libvps_hip.so (vps_spectrum_zimages: RCCL send / recv groups on the library's own stream)
