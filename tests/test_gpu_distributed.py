@@ -87,7 +87,21 @@ def _rccl_worker(rank, port, N, Np, out_dir):
         tab = pipe.finish(*pipe.accumulate_zimages([z[0], z[1], z[2]]))   # fused path: chunked complex all-to-alls + all-reduces over RCCL
         fields = K.deposit_field(d[0], d[1], d[2], N, 1.0, 0, N, device.VELOCITY)
         tab2 = pipe.finish(*pipe.accumulate([fields[0], fields[1], fields[2]]))
-        np.save(os.path.join(out_dir, "tab_rccl.npy"), np.stack([tab, tab2]))
+        # field-parallel reductions over RCCL: SUM of the float64 view, MAX of the int64 view of the one accumulator buffer
+        # (a one-rank group, the early return for a single field rank switched off)
+        fcomm = device.FieldComm()
+        assert fcomm.backend == "nccl" and (fcomm.world, fcomm.field_world) == (1, 1)
+        fcomm.field_world = 2                      # reductions are issued; over one rank they are the identity
+        fpipe = device.PowerPipeline(N, 1.0, kernels=K, comm=fcomm)
+        psum, nsample = fpipe.new_accumulators()
+        with K.binning_only():
+            spec, nyq = K.deposit_fft_zy(d[0], d[1], d[2], N, 1.0, 0, N, device.VELOCITY, component=(0, 1))
+        fpipe.accumulate_spectra(spec, nyq, psum, nsample)
+        with K.binning_only():
+            spec, nyq = K.deposit_fft_zy(d[0], d[1], d[2], N, 1.0, 0, N, device.VELOCITY, component=2)
+        fpipe.accumulate_spectra(spec, nyq, psum, nsample, count=False)
+        tab3 = fpipe.finish(psum, nsample)
+        np.save(os.path.join(out_dir, "tab_rccl.npy"), np.stack([tab, tab2, tab3]))
     finally:
         dist.destroy_process_group()
 
