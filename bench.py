@@ -624,6 +624,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
             owl = Workload(K, ocomm, N, L, route, quantities, flavour, dpos, dvel, drho)
             if other == "fields":
                 K.workspace("fused", K.lib.vps_deposit_fft_zy_workspace_bytes(dpos.shape[0], N, N))
+            otabs = owl.step()      # (first warm-up step: the step's own buffers; sizes are the same on every rank)
         except torch.OutOfMemoryError:
             ok_local = 0
         okt = torch.tensor([ok_local], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
@@ -631,7 +632,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
         if int(okt.item()) == 0:
             res["alternative"] = {"decomposition": other, "skipped": "a rank could not allocate its buffers"}
         else:
-            for _ in range(max(warmup, 1)):
+            for _ in range(max(warmup - 1, 0)):
                 otabs = owl.step()
             barrier()
             t0 = time.perf_counter()
