@@ -217,6 +217,28 @@ class Workload:
             return "exact-NN resample (library lattice) with v, m formed in its epilogue -> z pass (p = v*m formed in the pass)"
         return "exact-NN resample (script lattice, raw velocities) -> grid -> z pass"
 
+    def _quantity_accs(self):
+        """One (buffer, shell sums, shell counts) triple per quantity for the CURRENT pipeline, zeroed."""
+        import torch
+        if getattr(self, "_qacc_pipe", None) is not self.pipe:
+            nb = self.pipe.nbins
+            self._qacc = []
+            for _ in self.quantities:
+                buf = self.K.zeros((2 * nb,), torch.float64)
+                self._qacc.append((buf, buf[:nb], buf[nb:].view(torch.int64)))
+            self._qacc_pipe = self.pipe
+        for buf, _, _ in self._qacc:
+            buf.zero_()
+        return self._qacc
+
+    def _quantity_tables(self, accs):
+        out = {}
+        for i, q in enumerate(self.quantities):
+            tab = self.pipe.finish(accs[i][1], accs[i][2])     # all-reduce, D2H, table
+            tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2              # interp.py:590 / script:434
+            out[q] = tab
+        return out
+
     def _table(self):
         tab = self.pipe.finish(self.psum, self.nsample)     # all-reduce, D2H, table
         tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2              # interp.py:590 / script:434
@@ -250,8 +272,8 @@ class Workload:
             # quantity adds the shell sums of all ranks (a vector quantity's |F|^2 are summed over components anyway)
             token = None
             self.pipe.prepare()
-            for q in self.quantities:
-                self.acc_buf.zero_()
+            accs = self._quantity_accs()
+            for i, q in enumerate(self.quantities):
                 comps = [c for (qq, c) in self.my_units if qq == q]
                 if comps:       # this rank's components of q in ONE launch (None: the energy field)
                     nc = len(comps)
@@ -260,9 +282,24 @@ class Workload:
                                                      spec=self.spec[:nc], nyq=self.nyq[:nc], reuse_sort=token,
                                                      component=None if comps[0] is None else comps)
                     token = K.fused_token()
-                    self.pipe.accumulate_spectra(spec, nyq, self.psum, self.nsample)
-                out[q] = self._table()
-            return out
+                    self.pipe.accumulate_spectra(spec, nyq, accs[i][1], accs[i][2])
+            return self._quantity_tables(accs)      # (reductions and copies after every launch of the step has been issued)
+        if self.route == "ngp" and self.fused and not self.pipe.chunked:
+            # one GPU: deposit + field algebra + z pass in one kernel (pencil buckets), then the y passes (their output goes
+            # straight into the binning x pass: rows beyond the last shell edge are not stored); the second and third quantity
+            # of a step reuse the first one's bucket sort.  Every quantity has its own accumulators, so the whole step is
+            # issued before the first table is copied back (the host never waits between quantities).
+            token = None
+            self.pipe.prepare()
+            accs = self._quantity_accs()
+            for i, q in enumerate(self.quantities):
+                qi, nc = dev.QUANTITY[q], NCOMP[q]
+                with K.binning_only():
+                    spec, nyq = K.deposit_fft_zy(self.pos, self.vel, self.rho, N, L, x0, nx, qi,
+                                                 spec=self.spec[:nc], nyq=self.nyq[:nc], reuse_sort=token)
+                token = K.fused_token()
+                self.pipe.accumulate_spectra(spec, nyq, accs[i][1], accs[i][2])
+            return self._quantity_tables(accs)
         if self.route == "ngp":
             token = None
             for q in self.quantities:
@@ -274,16 +311,6 @@ class Workload:
                                         slab_particles=self.slab_particles)
                     token = K.fused_token()
                     self.pipe.accumulate_zimages([z[i] for i in range(nc)], self.psum, self.nsample)
-                elif self.fused:
-                    # deposit + field algebra + z pass in one kernel (pencil buckets), then the y passes (their output goes
-                    # straight into the binning x pass: rows beyond the last shell edge are not stored);
-                    # the second and third quantity of a step reuse the first one's bucket sort
-                    self.pipe.prepare()
-                    with K.binning_only():
-                        spec, nyq = K.deposit_fft_zy(self.pos, self.vel, self.rho, N, L, x0, nx, qi,
-                                                     spec=self.spec[:nc], nyq=self.nyq[:nc], reuse_sort=token)
-                    token = K.fused_token()
-                    self.pipe.accumulate_spectra(spec, nyq, self.psum, self.nsample)
                 else:
                     g = K.deposit_field(self.pos, self.vel, self.rho, N, L, x0, nx, qi, out=self.grid[:nc])
                     self.pipe.accumulate([g[i] for i in range(nc)], self.psum, self.nsample)
