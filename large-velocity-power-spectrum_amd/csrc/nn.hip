@@ -54,23 +54,34 @@ __global__ void nn_init_header(NnHeader* h) {
 template <typename F>
 __global__ void __launch_bounds__(256) nn_bbox_kernel(const F* __restrict__ pos, long long np, NnHeader* h) {
   double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  // four particles per thread and trip: twelve loads in flight (one per trip left the pass latency bound: 0.8 ms for 0.6 GB)
+  // A thread takes FOUR consecutive particles per trip = 12 consecutive coordinates = three 16-byte loads (float; six for double):
+  // whole cache lines per wave instruction.  (One particle per thread -- three 4-byte loads 12 bytes apart, every line touched by
+  // three instructions -- left the pass latency bound: 0.8 ms for 0.6 GB; four strided particles per trip 0.58 ms.)
+  typedef typename std::conditional<sizeof(F) == 4, float4, double2>::type V;
+  constexpr int PER = sizeof(V) / sizeof(F), NV = 12 / PER;
+  // (a coordinate array that does not start on a 16-byte boundary -- a slice handed in through the C ABI -- goes through the
+  //  scalar tail below, whole)
+  const bool aligned = (reinterpret_cast<unsigned long long>(pos) & 15ull) == 0;
+  const long long ngroups = aligned ? np / 4 : 0;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < np; i0 += 4 * stride) {
-    F v[4][3];
+  const V* pv = reinterpret_cast<const V*>(pos);
+  for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += stride) {
+    V v[NV];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long long i = i0 + u * stride;
+    for (int u = 0; u < NV; ++u) v[u] = pv[gi * NV + u];
+    const F* f = reinterpret_cast<const F*>(v);
 #pragma unroll
-      for (int a = 0; a < 3; ++a) v[u][a] = i < np ? pos[i * 3 + a] : pos[i0 * 3 + a];
+    for (int j = 0; j < 12; ++j) {
+      lo[j % 3] = fmin(lo[j % 3], (double)f[j]);
+      hi[j % 3] = fmax(hi[j % 3], (double)f[j]);
     }
+  }
+  for (long long i = 4 * ngroups + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += stride) {   // the last np % 4
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        lo[a] = fmin(lo[a], (double)v[u][a]);
-        hi[a] = fmax(hi[a], (double)v[u][a]);
-      }
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fmin(lo[a], (double)pos[i * 3 + a]);
+      hi[a] = fmax(hi[a], (double)pos[i * 3 + a]);
+    }
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -79,13 +90,27 @@ __global__ void __launch_bounds__(256) nn_bbox_kernel(const F* __restrict__ pos,
       hi[a] = fmax(hi[a], __shfl_down(hi[a], off, 64));
     }
   }
+  // one set of atomics per WORKGROUP: returning atomics on one word peak near 90 per microsecond, and the six words share a
+  // cache line -- one set per wave (8192 waves) was most of the pass: 0.6 ms for 0.6 GB
+  __shared__ double red[4][6];
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      if (lo[a] <= hi[a]) {
-        atomicMin(&h->bmin[a], f64_to_ordered(lo[a]));
-        atomicMax(&h->bmax[a], f64_to_ordered(hi[a]));
-      }
+      red[threadIdx.x >> 6][a] = lo[a];
+      red[threadIdx.x >> 6][3 + a] = hi[a];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    double l0 = red[0][a], h0 = red[0][3 + a];
+    for (int w = 1; w < 4; ++w) {
+      l0 = fmin(l0, red[w][a]);
+      h0 = fmax(h0, red[w][3 + a]);
+    }
+    if (l0 <= h0) {
+      atomicMin(&h->bmin[a], f64_to_ordered(l0));
+      atomicMax(&h->bmax[a], f64_to_ordered(h0));
     }
   }
 }
@@ -1682,7 +1707,7 @@ int nn_run(vps_ctx* ctx, const F* pos, const float* payload, int64_t np, int C, 
   {
     vps_launch_timer tm(ctx, VPS_K_NN_BUILD);
     hipLaunchKernelGGL(nn_init_header, dim3(1), dim3(64), 0, ctx->stream, hdr);
-    const unsigned rb = pblocks < 2048u ? pblocks : 2048u;
+    const unsigned rb = pblocks < 1024u ? pblocks : 1024u;
     hipLaunchKernelGGL(nn_bbox_kernel<F>, dim3(rb), dim3(256), 0, ctx->stream, pos, (long long)np, hdr);
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());

@@ -57,15 +57,23 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int a = 0; a < 4; ++a) w[a] += __shfl_down(w[a], off, 64);
   }
+  // one set of atomics per WORKGROUP, not per wave: the seven words share a cache line, and returning atomics on one line
+  // serialise at the memory side (the NN bounding-box pass spent most of its time there, nn.hip)
+  __shared__ double red[4][7];
   if ((threadIdx.x & 63) == 0) {
-    if (want_min) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
-        if (lo[a] != INFINITY) atomicMin(&s->vmin[a], ordered_of(lo[a]));
-    }
-    if (want_bulk) {
+    for (int a = 0; a < 3; ++a) red[threadIdx.x >> 6][a] = lo[a];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) atomicAdd(&s->wsum[a], w[a]);
+    for (int a = 0; a < 4; ++a) red[threadIdx.x >> 6][3 + a] = w[a];
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int a = threadIdx.x;
+    if (a < 3) {
+      const double m = fmin(fmin(red[0][a], red[1][a]), fmin(red[2][a], red[3][a]));
+      if (want_min && m != INFINITY) atomicMin(&s->vmin[a], ordered_of(m));
+    } else if (want_bulk) {
+      atomicAdd(&s->wsum[a - 3], (red[0][a] + red[1][a]) + (red[2][a] + red[3][a]));
     }
   }
 }
@@ -144,9 +152,15 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int a = 0; a < 5; ++a) w[a] += __shfl_down(w[a], off, 64);
   }
+  __shared__ double red[4][5];     // (one set of atomics per workgroup: see prep_reduce)
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int a = 0; a < 5; ++a) atomicAdd(&out[a], w[a]);
+    for (int a = 0; a < 5; ++a) red[threadIdx.x >> 6][a] = w[a];
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const int a = threadIdx.x;
+    atomicAdd(&out[a], (red[0][a] + red[1][a]) + (red[2][a] + red[3][a]));
   }
 }
 

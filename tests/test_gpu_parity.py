@@ -821,3 +821,31 @@ def test_single_component_launch_equals_the_vector_launch(K, N, quantity, flags)
         K.deposit_fft_zy(dpos, dvel, drho, N, 1.0, 0, N, q, component=(1, 1))
     with pytest.raises(Exception):     # the library refuses the flag for energy as well
         K.deposit_fft_zy(dpos, dvel, drho, N, 1.0, 0, N, device.ENERGY, flags=(1 << 4))
+
+
+def test_position_arrays_off_a_16_byte_boundary(K):
+    """Coordinate arrays that start 12 bytes into an allocation (a slice handed in through the C ABI): the passes that read
+    positions with 16-byte loads (NN bounding box, slab filter) must not care.  NN indices, slab counts and the slab filter's
+    z image against the same particles in an aligned copy."""
+    from vpower import device, synth
+    N, Np = 64, 150001
+    pos, vel, mass, dens = synth.particles(91, Np + 1, 1.0)
+    dp, dv, dr = K.to_device(pos), K.to_device(vel), K.to_device(dens)
+    p1, v1, r1 = dp[1:], dv[1:], dr[1:]                      # 12 bytes (positions, velocities) / 4 bytes (densities) in
+    assert p1.data_ptr() % 16 != 0 and p1.is_contiguous()
+    p0, v0, r0 = p1.clone(), v1.clone(), r1.clone()
+    assert p0.data_ptr() % 16 == 0
+    ax = np.linspace(0.5 / N, 1.0 + 0.5 / N, N)
+    pay = K.density_velocity_vector(v0, r0)
+    g0, i0 = K.nn_resample(p0, pay, (ax, ax, ax), 0, N, want_index=True)
+    g1, i1 = K.nn_resample(p1, K.density_velocity_vector(v1, r1), (ax, ax, ax), 0, N, want_index=True)
+    assert torch.equal(i0, i1) and torch.equal(g0, g1)
+    ref = orc.exact_nn_lattice(pos[1:], ax, ax, ax)
+    assert np.array_equal(i1.cpu().numpy().ravel(), ref)
+    x0, nx = 16, 16
+    c0, c1 = K.count_in_slab(p0, N, 1.0, x0, nx), K.count_in_slab(p1, N, 1.0, x0, nx)
+    assert c0 == c1 == int(np.sum((orc.cell_index(pos[1:, 0], N, 1.0) >= x0) & (orc.cell_index(pos[1:, 0], N, 1.0) < x0 + nx)))
+    z0 = K.deposit_fft_z(p0, v0, r0, N, 1.0, x0, nx, device.MOMENTUM, slab_particles=c0).clone()
+    z1 = K.deposit_fft_z(p1, v1, r1, N, 1.0, x0, nx, device.MOMENTUM, slab_particles=c1)
+    rms = float(torch.sqrt(torch.mean(torch.abs(z0) ** 2)))
+    assert torch.allclose(torch.view_as_real(z1), torch.view_as_real(z0), rtol=1e-5, atol=1e-6 * rms)
