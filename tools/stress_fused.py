@@ -10,7 +10,7 @@ cases = [(64, 64, 0, 3000, "uniform"), (256, 64, 128, 2_000_000, "clump"), (512,
          (512, 16, 496, 5_000_000, "clump"), (1024, 64, 512, 30_000_000, "uniform"), (2048, 16, 64, 20_000_000, "sheet"),
          (128, 128, 0, 5_000_000, "onecell"), (512, 32, 0, 1000, "outside"),
          (192, 192, 0, 2_000_000, "clump"), (384, 96, 288, 3_000_000, "uniform"), (768, 32, 100, 5_000_000, "clump"),
-         (1536, 16, 64, 20_000_000, "sheet")]
+         (1536, 16, 64, 20_000_000, "sheet"), (4096, 8, 2040, 20_000_000, "sheet"), (2048, 8, 0, 30_000_000, "clump")]
 worst = 0.0
 for N, nx, x0, Np, kind in cases:
     pos = rng.random((Np, 3)).astype(np.float32)
@@ -25,16 +25,17 @@ for N, nx, x0, Np, kind in cases:
     dp = K.to_device(pos)
     dv = K.to_device(rng.standard_normal((Np, 3)).astype(np.float32))
     dr = K.to_device(np.exp(rng.standard_normal(Np)).astype(np.float32))
-    for q in (device.VELOCITY, device.MOMENTUM):
+    for q in (device.VELOCITY, device.MOMENTUM, device.ENERGY):
         fields = K.deposit_field(dp, dv, dr, N, 1.0, x0, nx, q)
         spec, nyq = K.deposit_fft_zy(dp, dv, dr, N, 1.0, x0, nx, q)
-        for c in range(3):
+        for c in range(1 if q == device.ENERGY else 3):
             s_ref, n_ref = K.fft_zy(fields[c], N, nx)
             scale = float(s_ref.abs().pow(2).mean().sqrt()) or 1.0
             e = max(float((spec[c] - s_ref).abs().max()), float((nyq[c] - n_ref).abs().max())) / scale
             worst = max(worst, e)
             # millions of float32 adds into ONE cell in two different orders: 1e-4 is rounding, not a bug
-            assert e < (1e-3 if kind == "onecell" else 5e-5), (N, nx, x0, Np, kind, q, c, e)
+            # (max over ~1e8 modes of float32 transform noise of two different factorisations: ~6 sigma; 4096-point lines add a stage)
+            assert e < (1e-3 if kind == "onecell" else 1.2e-4 if N >= 4096 else 5e-5), (N, nx, x0, Np, kind, q, c, e)
     print("ok", N, nx, x0, Np, kind, flush=True)
     del dp, dv, dr, fields, spec, nyq
     torch.cuda.empty_cache()
