@@ -806,6 +806,11 @@ def main(argv=None):
                                      and fields_possible(K, N_, synth.WORKLOADS[args.config][0], synth.WORKLOADS[args.config][1],
                                                          args.unfused)) else "slab"
     if decomposition == "fields" and world > 1:
+        if args.decomposition == "fields" and args.config in synth.CONFIGS and not fields_possible(
+                K, int(os.environ.get("VPS_BENCH_GRID", synth.CONFIGS[args.config][0])), synth.WORKLOADS[args.config][0],
+                synth.WORKLOADS[args.config][1], args.unfused):
+            raise SystemExit("--decomposition fields: %s does not fit -- every rank would hold whole grids (fused NGP path, about "
+                             "26 N^3 bytes of one GPU's HBM); use --decomposition slab" % args.config)
         comm = device.FieldComm()
     elif os.environ.get("VPS_BENCH_TRANSPORT") == "library" and world > 1 and backend == "nccl":
         # the exchange inside libvps_hip.so (vps_spectrum_zimages: RCCL send / recv groups on the library's own stream)
