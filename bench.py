@@ -833,6 +833,10 @@ def main(argv=None):
     if cfg not in synth.CONFIGS:
         raise SystemExit("unknown config %s" % cfg)
     single = world == 1 and comm.world == 1
+    if single and not os.environ.get("VPS_BENCH_GRID") and (
+            26.0 * float(synth.CONFIGS[cfg][0]) ** 3 >= 0.78 * torch.cuda.get_device_properties(local).total_memory):
+        raise SystemExit("%s: a %d^3 grid does not fit one GPU -- run it on its ranks (--gpus 8) or time one rank's share "
+                         "(--emulate-ranks 8)" % (cfg, synth.CONFIGS[cfg][0]))
     res = run_config(args, cfg, K, comm, world, rank, backend, args.steps, args.warmup, args.profile_steps,
                      want_parity=not args.no_parity and (comm.world == world or getattr(comm, "field_world", 1) == world),
                      want_cpu=single and not args.no_cpu_baseline)
