@@ -214,6 +214,8 @@ class Workload:
                 return "fused deposit+z pass (pencil buckets), one scalar field per launch; fields dealt out over the ranks"
             return "fused deposit+z pass (pencil buckets)" if self.fused else "deposit -> grid -> z pass"
         if self.route == "nn":
+            if len(self.quantities) == 1:
+                return "exact-NN resample (library lattice) with the %s field(s) formed in its epilogue -> z pass" % self.quantities[0]
             return "exact-NN resample (library lattice) with v, m formed in its epilogue -> z pass (p = v*m formed in the pass)"
         return "exact-NN resample (script lattice, raw velocities) -> grid -> z pass"
 
@@ -315,6 +317,16 @@ class Workload:
                     g = K.deposit_field(self.pos, self.vel, self.rho, N, L, x0, nx, qi, out=self.grid[:nc])
                     self.pipe.accumulate([g[i] for i in range(nc)], self.psum, self.nsample)
                 out[q] = self._table()
+            return out
+        if self.route == "nn" and len(self.quantities) == 1:
+            # one quantity (C3): the search's epilogue writes the fields its spectrum transforms (vps_nn_resample_quantity) --
+            # no mass channel, no weighted z pass; what `gp.ann_interp_to_field(N).spctrm(q)` runs (vpower/interp.py)
+            q = self.quantities[0]
+            payload = K.density_velocity_vector(self.vel, self.rho)              # interp.py:199-213
+            f, _ = K.nn_resample_quantity(self.pos, payload, self.axes, x0, nx, L / N, dev.QUANTITY[q], out=self.grid[:NCOMP[q]])
+            self.acc_buf.zero_()
+            self.pipe.accumulate([f[i] for i in range(NCOMP[q])], self.psum, self.nsample)
+            out[q] = self._table()
             return out
         if self.route == "nn":
             payload = K.density_velocity_vector(self.vel, self.rho)              # interp.py:199-213
@@ -510,11 +522,12 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     elif route == "ngp" and wl.fused:
         step_bytes["fft_z"] = sum(NCOMP[q] * 8.0 * nx * N * (NH + 1) + 20.0 * Nps for q in quantities)
     else:
-        wread = 4.0 * nx * N * N if (route == "nn" and "momentum" in quantities) else 0.0
+        wread = 4.0 * nx * N * N if (route == "nn" and "momentum" in quantities and len(quantities) > 1) else 0.0
         step_bytes["fft_z"] = nfields * (4.0 * nx * N * N + wread + 8.0 * nx * N * (NH + 1))
     if route != "ngp":
         C_ = 4 if route == "nn" else 3
-        step_bytes["nn_query"] = Np * (12.0 + 4 * C_) + 4.0 * C_ * nx * N * N
+        Cout = nfields if (route == "nn" and len(quantities) == 1) else C_     # one quantity: only its fields are written
+        step_bytes["nn_query"] = Np * (12.0 + 4 * C_) + 4.0 * Cout * nx * N * N
     launches_per_step = {k: max(len(v) // nst, 1) for k, v in main.items() if len(v)}
     kms = {k: float(np.sum(v)) / nst for k, v in main.items() if len(v)}        # ms per step in main launches
     if not kms:      # (a field-parallel rank beyond the last field: it only takes part in the reductions; never rank 0)
@@ -567,6 +580,11 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
                      "avg_launch_ms": kms[dom] / launches_per_step[dom],
                      "launches_per_step": launches_per_step[dom]},
         "per_kernel_frac_of_hbm_peak": {k: step_bytes[k] / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS for k in kms},
+        **({"nn_query_note": "the search writes only the %d field(s) of the one quantity (vps_nn_resample_quantity): %.1f GB of algorithmic "
+                             "bytes; on SURVEY.md 8(d) A2's four BoxField channels (%.1f GB) the same launch would read %.3f of peak"
+                             % (nfields, step_bytes["nn_query"] / 1e9, (Np * 28.0 + 16.0 * nx * N * N) / 1e9,
+                                (Np * 28.0 + 16.0 * nx * N * N) / (kms["nn_query"] * 1e-3) / 1e9 / HBM_PEAK_GBS)}
+           if (route == "nn" and len(quantities) == 1 and "nn_query" in kms) else {}),
         "kept_row_fraction": keep,
         "launch_ms": {k: [round(float(x), 3) for x in v[:12]] for k, v in per.items() if len(v) and k in ("nn_query", "nn_build")},
     }

@@ -65,7 +65,7 @@ int vps_destroy(vps_ctx* ctx);
 const char* vps_last_error(const vps_ctx* ctx);   /* ctx may be NULL: global slot */
 int vps_set_stream(vps_ctx* ctx, void* hip_stream);
 int vps_sync(vps_ctx* ctx);
-int vps_version(void);                            /* ABI version, currently 3       */
+int vps_version(void);                            /* ABI version, currently 4       */
 /* Tuning / test switches, process-wide.  The library never reads the environment: a stray variable in a user's job cannot
  * change a code path; the host sets what it wants explicitly (vpower/_ffi.py maps VPS_OPT_<NAME> variables once, at load,
  * and lists them in _ffi.OPTIONS).  Names: no_fast_binning, no_pair_binning, nn_query_centric, nn_column, nn_build_atomic, nn_kappa, nn_stats,
@@ -197,6 +197,16 @@ int vps_nn_resample_field(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, con
                           int64_t np, const double* qx_host, int nqx, const double* qy_host, int nqy,
                           const double* qz_host, int nqz, int x0, int nx, double Lcell,
                           float* out_dev, int32_t* nn_idx_dev, void* work_dev);
+
+/* ... and with the algebra of BoxField.spctrm's quantity as well (interp.py:501-557): out_dev [ncomp][nx][nqy][nqz] holds what
+ * the spectrum of `quantity` transforms -- VPS_VELOCITY: v (3 channels); VPS_MOMENTUM: p = v * mass (3; with
+ * VPS_FLAG_REFERENCE_MOMENTUM_BUG py = pz = px, interp.py:523-525); VPS_ENERGY: E = mass |v|^2 (1); VPS_VM: v and mass (4, =
+ * vps_nn_resample_field) -- v = rho v / rho and mass = rho Lcell^3 of the nearest particle, rounded as the reference rounds them.
+ * For `ann_interp_to_field(N).spctrm(q)`: no fourth channel is written and the z pass reads one array per component. */
+int vps_nn_resample_quantity(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* rhov_dev,
+                             int64_t np, const double* qx_host, int nqx, const double* qy_host, int nqy,
+                             const double* qz_host, int nqz, int x0, int nx, double Lcell, int quantity, int flags,
+                             float* out_dev, int32_t* nn_idx_dev, void* work_dev);
 
 /* ---- stage A3: field algebra ------------------------------------------- */
 /* chans_dev: [4][ncell] = rho*vx, rho*vy, rho*vz, rho (density_velocity_vector,

@@ -73,7 +73,7 @@ double vps_option(const char* name, double dflt) {
 
 extern "C" {
 
-int vps_version(void) { return 3; }
+int vps_version(void) { return 4; }
 
 int vps_set_option(const char* name, double value) {
   if (!name) return vps_fail(nullptr, VPS_ERR_ARG, "vps_set_option: null name");

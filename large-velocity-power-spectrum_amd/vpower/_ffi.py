@@ -57,6 +57,8 @@ SYMBOLS = (
     ("vps_nn_workspace_bytes", C.c_size_t, (_i64, C.c_int, _i64)),
     ("vps_nn_resample_field", C.c_int, (_vp, _vp, C.c_int, _vp, _i64, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int,
                                         C.c_double, _vp, _vp, _vp)),
+    ("vps_nn_resample_quantity", C.c_int, (_vp, _vp, C.c_int, _vp, _i64, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int,
+                                           C.c_double, C.c_int, C.c_int, _vp, _vp, _vp)),
     ("vps_nn_resample", C.c_int, (_vp, _vp, C.c_int, _vp, _i64, C.c_int, _dp, C.c_int, _dp, C.c_int,
                                   _dp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp)),
     ("vps_field_algebra", C.c_int, (_vp, C.c_int, C.c_int, C.c_double, _vp, _i64)),

@@ -381,6 +381,24 @@ class HipKernels:
                                                  self._ptr(idx), self._ptr(work)))
         return out, idx
 
+    def nn_resample_quantity(self, pos, rhov, axes, x0, nx, Lcell, quantity, flags=0, out=None, want_index=False):
+        """Exact-NN resampling of [rho v, rho] straight into the fields the spectrum of `quantity` transforms
+        (vps_nn_resample_quantity): VELOCITY -> [3, ...] v; MOMENTUM -> [3, ...] p = v * mass; ENERGY -> [1, ...] mass |v|^2;
+        VM -> [4, ...] (= nn_resample_field)."""
+        self._stream()
+        ax = [np.ascontiguousarray(a, dtype=np.float64) for a in axes]
+        nout = 1 if quantity == ENERGY else (4 if quantity == VM else 3)
+        if out is None:
+            out = self.empty((nout, nx, len(ax[1]), len(ax[2])), torch.float32)
+        idx = self.empty((nx, len(ax[1]), len(ax[2])), torch.int32) if want_index else None
+        kind = self._pos_kind(pos)
+        work = self.workspace("nn", self.lib.vps_nn_workspace_bytes(pos.shape[0], kind, nx * len(ax[1]) * len(ax[2])))
+        self._chk(self.lib.vps_nn_resample_quantity(self.ctx, self._ptr(pos), kind, self._ptr(rhov, torch.float32),
+                                                    pos.shape[0], _ffi.as_dp(ax[0]), len(ax[0]), _ffi.as_dp(ax[1]), len(ax[1]),
+                                                    _ffi.as_dp(ax[2]), len(ax[2]), x0, nx, float(Lcell), int(quantity), int(flags),
+                                                    self._ptr(out), self._ptr(idx), self._ptr(work)))
+        return out, idx
+
     def field_algebra(self, chans, quantity, flags, Lcell):
         self._stream()
         ncell = chans[0].numel()

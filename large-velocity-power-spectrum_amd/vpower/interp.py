@@ -203,8 +203,9 @@ class GasParticles:
         k = _kernels()
         Lcell = self.Lbox / Nsize
         ax = _lattice_axis(self.Lbox, Nsize)
-        grid, _ = k.nn_resample_field(self._device_pos(k), self._device_payload(k), (ax, ax, ax), 0, Nsize, Lcell)
-        return BoxField._from_device(grid, Lcell)
+        # The four grids are built on first use: `ann_interp_to_field(N).spctrm(q)`, the usual composition, resamples
+        # straight into the fields of q (vps_nn_resample_quantity: no mass channel written, no weighted z pass).
+        return BoxField._from_neighbours((self._device_pos(k), self._device_payload(k), ax), Nsize, Lcell)
 
     def deposit_to_field(self, Nsize, assignment="ngp"):
         """NGP composition the reference leaves to the caller: deposit_to_grid of
@@ -280,7 +281,24 @@ class BoxField:
         self.Lbox = Lbox               # as given (Nsize * Lcell may differ in the last bit)
         return self
 
+    @classmethod
+    def _from_neighbours(cls, nn_src, Nsize, Lcell):
+        """Lazy exact-NN field of nn_src = (device positions, device [rho v, rho], lattice axis)."""
+        self = cls.__new__(cls)
+        self.Lcell = Lcell
+        self._host = {}
+        self._chans = None
+        self._nn_src = nn_src
+        self._nn_spectra = 0
+        self.Nsize = Nsize
+        self.Lbox = Nsize * Lcell
+        return self
+
     def _materialise(self):
+        nn = getattr(self, "_nn_src", None)
+        if nn is not None and self._chans is None and not self._host:
+            self._chans, _ = _kernels().nn_resample_field(nn[0], nn[1], (nn[2], nn[2], nn[2]), 0, self.Nsize, self.Lcell)
+        self._nn_src = None
         src = getattr(self, "_src", None)
         if src is not None and self._chans is None and not self._host:
             self._chans = _kernels().deposit_field(src[0], src[1], src[2], self.Nsize, self.Lbox, 0, self.Nsize, _dev.VM)
@@ -382,6 +400,15 @@ class BoxField:
             tab = pipe.finish(*pipe.accumulate_spectra(spec, nyq))
             tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2
             return PowerSpectrum(tab)
+        nn = getattr(self, "_nn_src", None)
+        if nn is not None and self._nn_spectra == 0:
+            # neighbour-backed field, first spectrum: the search writes the fields of this quantity directly.  (A second
+            # quantity builds the four grids once -- one more search -- and every later one is served from them.)
+            self._nn_spectra = 1
+            flags = _dev.FLAG_REFERENCE_MOMENTUM_BUG if (quantity == "momentum" and REFERENCE_COMPAT["momentum_bug"]) else 0
+            f, _ = k.nn_resample_quantity(nn[0], nn[1], (nn[2], nn[2], nn[2]), 0, self.Nsize, self.Lcell,
+                                          _dev.QUANTITY[quantity], flags)
+            return PowerSpectrum(pipe.spectrum([f[i] for i in range(f.shape[0])]))
         if quantity == "momentum":
             # p_c = v_c * mass is formed inside the z pass (two reads per line instead of an algebra pass)
             ch = self._device_chans(k)

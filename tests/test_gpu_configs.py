@@ -154,21 +154,28 @@ def test_config3_full_size_momentum_properties(K):
     tab = wl.step()["momentum"]
     assert np.array_equal(tab[:, 3], _shell_counts_exact(K, wl.pipe))
     assert np.isfinite(tab[:, 2]).all() and (tab[:, 2] > 0).all()
-    g = wl.grid                                     # vx, vy, vz, mass after the step's field algebra
-    # every cell holds the payload of SOME particle: mass / Lcell^3 is one of the particle densities
-    rho_cells = (g[3, ::97, ::89, ::83] / (L / N) ** 3).reshape(-1)
+    g = wl.grid[:3]                                 # px, py, pz: the search's epilogue wrote the momentum field itself
+    # the BoxField form of the same search: every cell holds the payload of SOME particle (mass / Lcell^3 is one of the
+    # particle densities), and the momentum written directly equals v * mass of that form
+    vm, _ = K.nn_resample_field(dpos, K.density_velocity_vector(dvel, drho), wl.axes, 0, N, L / N)
+    rho_cells = (vm[3, ::97, ::89, ::83] / (L / N) ** 3).reshape(-1)
     srt = torch.sort(drho).values
     pos_ = torch.searchsorted(srt, rho_cells).clamp(1, Np - 1)
     near = torch.minimum((srt[pos_] - rho_cells).abs(), (srt[pos_ - 1] - rho_cells).abs())
     assert float((near / rho_cells).max().item()) < 1e-6
+    for c in range(3):
+        for i in range(0, N, 128):
+            want_p = vm[c, i:i + 128] * vm[3, i:i + 128]
+            assert torch.allclose(g[c, i:i + 128], want_p, rtol=1e-6, atol=0)
+    del vm
     # Parseval, all modes binned: sum Psum (2 pi/L)^3 = 0.5 sum_c (<p_c^2> - <p_c>^2)
     pall = _all_mode_pipeline(K, N, L)
-    t2 = pall.finish(*pall.accumulate([g[0], g[1], g[2]], weight=g[3]))
+    t2 = pall.finish(*pall.accumulate([g[0], g[1], g[2]]))
     want = 0.0
     for c in range(3):
         s = q = 0.0
         for i in range(0, N, 32):
-            d = g[c, i:i + 32].double() * g[3, i:i + 32].double()
+            d = g[c, i:i + 32].double()
             s += float(d.sum().item())
             q += float((d * d).sum().item())
         want += 0.5 * (q / N ** 3 - (s / N ** 3) ** 2)

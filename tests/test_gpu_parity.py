@@ -849,3 +849,39 @@ def test_position_arrays_off_a_16_byte_boundary(K):
     z1 = K.deposit_fft_z(p1, v1, r1, N, 1.0, x0, nx, device.MOMENTUM, slab_particles=c1)
     rms = float(torch.sqrt(torch.mean(torch.abs(z0) ** 2)))
     assert torch.allclose(torch.view_as_real(z1), torch.view_as_real(z0), rtol=1e-5, atol=1e-6 * rms)
+
+
+@pytest.mark.parametrize("N,Np", [(64, 50000), (128, 3000)])
+def test_nn_resample_quantity_forms(K, N, Np):
+    """vps_nn_resample_quantity: the fields a spectrum transforms, written by the search's epilogue (column kernel, scalar
+    epilogue, float64 fallback alike) -- against the BoxField form (v, mass) of the same search and the field algebra on it;
+    the neighbour indices are the same; and the library path `ann_interp_to_field(N).spctrm(q)` that uses it against the oracle
+    (first quantity: direct form; second: grids built once)."""
+    from vpower import device, interp, synth
+    pos, vel, mass, dens = synth.particles(57, Np, 1.0)
+    dp, dv, dr = K.to_device(pos), K.to_device(vel), K.to_device(dens)
+    pay = K.density_velocity_vector(dv, dr)
+    ax = orc.lattice_axes_library(1.0, N)
+    Lcell = 1.0 / N
+    vm, i0 = K.nn_resample_field(dp, pay, (ax, ax, ax), 0, N, Lcell, want_index=True)
+    for q, flags in ((device.VELOCITY, 0), (device.MOMENTUM, 0), (device.MOMENTUM, device.FLAG_REFERENCE_MOMENTUM_BUG),
+                     (device.ENERGY, 0), (device.VM, 0)):
+        f, i1 = K.nn_resample_quantity(dp, pay, (ax, ax, ax), 0, N, Lcell, q, flags, want_index=True)
+        assert torch.equal(i0, i1)
+        if q == device.VM:
+            assert torch.equal(f, vm)
+            continue
+        want = K.field_algebra_out(vm, q, device.FLAG_INPUT_IS_VM | flags, Lcell) if q != device.VELOCITY else vm[:3]
+        assert f.shape[0] == want.shape[0] == (1 if q == device.ENERGY else 3)
+        assert torch.allclose(f, want, rtol=2e-6, atol=0)
+    # the library surface on top of it
+    gp = interp.GasParticles(pos, mass, dens, vel, Lbox=1.0)
+    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
+    grid, _ = orc.ann_interpolate(pos, (ax, ax, ax), vec, N)
+    v, m = orc.vm_from_vec_grid(grid, Lcell)
+    box = gp.ann_interp_to_field(N)
+    for q in ("momentum", "energy", "velocity"):            # first: direct form; then the materialised grids
+        sp = box.spctrm(q)
+        ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, Lcell, q)
+        assert np.array_equal(sp.Nsample, ref[:, 3]) and np.allclose(sp.Psum, ref[:, 2], rtol=2e-5, atol=0)
+    assert np.allclose(box.mass, m, rtol=1e-6)              # the grids exist now
