@@ -876,7 +876,7 @@ def main(argv=None):
                            want_parity=not args.no_parity, want_cpu=False)
             other[c] = {k: r[k] for k in ("ms_per_step", "value", "config", "particles_per_s", "fft_cells_per_s", "fft_stage",
                                           "kernel_ms_per_step", "roofline", "per_kernel_frac_of_hbm_peak", "parity", "full_size_check", "gridding",
-                                          "particles_per_s_sort_only", "gridding_note", "launch_ms") if k in r}
+                                          "particles_per_s_sort_only", "gridding_note", "launch_ms", "nn_query_note") if k in r}
             other[c]["steps"] = 5
         out["other_configs"] = other
     if rank == 0 and single and not args.no_cpu_baseline:
