@@ -236,7 +236,7 @@ class Workload:
     def _quantity_tables(self, accs):
         out = {}
         for i, q in enumerate(self.quantities):
-            tab = self.pipe.finish(accs[i][1], accs[i][2])     # all-reduce, D2H, table
+            tab = self.pipe.finish(accs[i][1], accs[i][2], buf=accs[i][0])     # all-reduce, one D2H copy, table
             tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2              # interp.py:590 / script:434
             out[q] = tab
         return out

@@ -1045,16 +1045,18 @@ class PowerPipeline:
         self._acc_buf = buf
         return buf[: self.nbins], buf[self.nbins:].view(torch.int64)
 
-    def finish(self, psum, nsample):
+    def finish(self, psum, nsample, buf=None):
         """Reduce over ranks and build the reference's (nbins,4) table
         [centre, P, Psum, Nsample] (interp.py:1478-1480 / parallel_optimized.py:185-188),
-        before the 4 pi k^2 factor."""
+        before the 4 pi k^2 factor.  buf: the ONE float64 buffer of 2 nbins words that psum and nsample are the two halves
+        of (as `new_accumulators` lays them out), if the caller keeps several such pairs: one device-to-host copy."""
         if isinstance(self.comm, LibraryComm):
             self.comm.all_reduce_shells(psum, nsample)
         else:
             self.comm.all_reduce_sum(psum)
             self.comm.all_reduce_sum(nsample)
-        buf = getattr(self, "_acc_buf", None)
+        if buf is None:
+            buf = getattr(self, "_acc_buf", None)
         if (buf is not None and psum.data_ptr() == buf.data_ptr()
                 and nsample.data_ptr() == buf.data_ptr() + 8 * self.nbins):
             host = buf.cpu()                         # one device-to-host copy for both accumulators
