@@ -670,12 +670,15 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
             if other == "fields":
                 K.workspace("fused", K.lib.vps_deposit_fft_zy_workspace_bytes(dpos.shape[0], N, N))
             otabs = owl.step()      # (first warm-up step: the step's own buffers; sizes are the same on every rank)
-        except torch.OutOfMemoryError:
-            ok_local = 0
+        except Exception as e:      # (out of memory, or anything else the first step of the other decomposition raises: the
+            ok_local = 0            #  run's own result must not be lost to the extra leg)
+            why = "%s: %s" % (type(e).__name__, str(e)[:160])
+        else:
+            why = None
         okt = torch.tensor([ok_local], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if int(okt.item()) == 0:
-            res["alternative"] = {"decomposition": other, "skipped": "a rank could not allocate its buffers"}
+            res["alternative"] = {"decomposition": other, "skipped": "a rank could not run its first step" + (" (%s)" % why if why else "")}
         else:
             for _ in range(max(warmup - 1, 0)):
                 otabs = owl.step()
