@@ -597,7 +597,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     # (the oracle cannot follow at this size; these are the size-independent properties of SURVEY.md section 4, computed with
     # torch float64 as the calculator: oracle/gpu_checks.py.  What they exercise are the kernels that dominate the timed
     # region -- wide y pass, 512-thread pencils, 64-bit sort keys, row-cut packing -- which the small oracle sample cannot.)
-    if not args.no_full_check and (G == world or fw == world) and not os.environ.get("VPS_BENCH_NOCHECK"):
+    if not args.no_full_check and (G == world or (fw > 1 and fw == world)) and not os.environ.get("VPS_BENCH_NOCHECK"):
         from oracle import gpu_checks as chk
         counts = chk.shell_counts_exact(K.device, N, wl.pipe.k2, wl.pipe.thr)
         full = {"nsample_exact": bool(all(np.array_equal(t[:, 3], counts) for t in tabs.values())),
@@ -659,7 +659,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     #  through ONE link; dealing the seven scalar fields out moves nbins numbers.  Whichever of the two is not the run's own
     #  decomposition is timed here on the same particles, and its tables are checked against the run's own, both at full size.)
     other = "slab" if fw > 1 else "fields"
-    can_other = (world > 1 and (G == world or fw == world) and not args.no_alternative
+    can_other = (world > 1 and (G == world or (fw > 1 and fw == world)) and not args.no_alternative
                  and fields_possible(K, N, route, quantities, args.unfused)
                  and (other == "fields" or (N % world == 0 and (N // 2) % world == 0)))
     if can_other:
@@ -719,7 +719,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     torch.cuda.empty_cache()
 
     # ---- the same step function on a small sample, against the oracle ----
-    if want_parity and (G == world or fw == world):
+    if want_parity and (G == world or (fw > 1 and fw == world)):
         Ns, Nps_ = sample_size(route, N, Np)
         while fw == 1 and Ns % (2 * world):      # (slabs: N/2 divisible by the ranks; field-parallel ranks hold whole grids)
             Ns *= 2
