@@ -885,3 +885,25 @@ def test_nn_resample_quantity_forms(K, N, Np):
         ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, Lcell, q)
         assert np.array_equal(sp.Nsample, ref[:, 3]) and np.allclose(sp.Psum, ref[:, 2], rtol=2e-5, atol=0)
     assert np.allclose(box.mass, m, rtol=1e-6)              # the grids exist now
+
+
+@pytest.mark.parametrize("argv,grid", [(["--no-other-configs"], "128"), (["--emulate-ranks", "4", "--no-other-configs"], "64"),
+                                       (["--config", "C3"], "64"), (["--config", "C5", "--emulate-ranks", "8"], "128")])
+def test_bench_command_line_paths(argv, grid, monkeypatch, capsys):
+    """bench.py's own control flow on one GPU at a rehearsal size (VPS_BENCH_GRID): the default line with its parity and
+    full-size checks, one emulated rank's share, the NN config, C5's emulated share -- each must print ONE JSON line with the
+    contract's keys (the checks inside assert parity themselves)."""
+    import json
+    import bench
+    monkeypatch.setenv("VPS_BENCH_GRID", grid)
+    monkeypatch.setenv("VPS_BENCH_PARTICLES", "200000")
+    bench.main(argv + ["--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in d
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "REHEARSAL" in d["config"]["deviation"]
+    if "--emulate-ranks" not in argv:
+        assert d["parity"]["nsample_equal"] and d["parity"]["psum_max_rel"] < 2e-5 and d["full_size_check"]["nsample_exact"]
