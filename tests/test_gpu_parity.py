@@ -888,7 +888,8 @@ def test_nn_resample_quantity_forms(K, N, Np):
 
 
 @pytest.mark.parametrize("argv,grid", [(["--no-other-configs"], "128"), (["--emulate-ranks", "4", "--no-other-configs"], "64"),
-                                       (["--config", "C3"], "64"), (["--config", "C5", "--emulate-ranks", "8"], "128")])
+                                       (["--config", "C3"], "64"), (["--config", "C5", "--emulate-ranks", "8"], "128"),
+                                       (["--config", "C1"], "64"), (["--config", "C2"], "128"), (["--unfused", "--no-other-configs"], "64")])
 def test_bench_command_line_paths(argv, grid, monkeypatch, capsys):
     """bench.py's own control flow on one GPU at a rehearsal size (VPS_BENCH_GRID): the default line with its parity and
     full-size checks, one emulated rank's share, the NN config, C5's emulated share -- each must print ONE JSON line with the
