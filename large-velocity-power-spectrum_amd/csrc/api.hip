@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 
 #include "vps_internal.h"
@@ -60,12 +61,19 @@ static const char* const k_option_names[] = {
     "sort_staged",        // 0: level-1 records scattered directly instead of LDS-staged runs (tests)
     "sort_atomic",        // 1: one returning global atomic per particle instead of the two-level sort (tests)
     "nn_ablate",          // timing-only builds (-DVPS_TIMING_VARIANTS): ignored otherwise
+    "x_wg_per_cu",        // persistent x pass: workgroups per CU (tuning / occupancy experiments; default: what LDS admits)
+    "comm_fail_send",     // n >= 1: the n-th ncclSend from now on fails without being issued (error-path tests; clears itself)
 };
 static std::map<std::string, double>& option_map() {
   static std::map<std::string, double> m;
   return m;
 }
+static std::mutex& option_lock() {   // (contexts of several host threads share the options)
+  static std::mutex mu;
+  return mu;
+}
 double vps_option(const char* name, double dflt) {
+  std::lock_guard<std::mutex> hold(option_lock());
   auto& m = option_map();
   auto it = m.find(name);
   return it == m.end() ? dflt : it->second;
@@ -79,6 +87,7 @@ int vps_set_option(const char* name, double value) {
   if (!name) return vps_fail(nullptr, VPS_ERR_ARG, "vps_set_option: null name");
   for (const char* n : k_option_names)
     if (!strcmp(n, name)) {
+      std::lock_guard<std::mutex> hold(option_lock());
       if (value != value) option_map().erase(name);   // NaN: back to the default
       else option_map()[name] = value;
       return VPS_OK;

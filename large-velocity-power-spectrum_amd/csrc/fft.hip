@@ -575,7 +575,7 @@ __device__ __forceinline__ void store_stream(cf* ptr, cf v) {
 //   X[k] = 0.5*((Z[k]+conj(Z[NC-k])) - i w^k (Z[k]-conj(Z[NC-k]))),  w = exp(-2 pi i/(2 NC)),
 // X[0] and X[NC] (Nyquist, stored apart) real.  Modes k and NC-k share Z[k], Z[NC-k] and, because
 // w^(NC-k) = -conj(w^k), the product w^k (Z[k]-conj(Z[NC-k])): one thread writes both.
-template <int NC, int T, int NT, bool BOUNDS>
+template <int NC, int T, int NT, bool BOUNDS, bool PLAIN = false>
 __device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf* __restrict__ tw_r2c, cf* out,
                                                long long out_ok, cf* nyq, int nlive) {
   // pair index kp = 0 .. NC/2 (the last one only for odd NC: for even NC the self-paired mode NC/2 rides with kp = 0)
@@ -610,8 +610,52 @@ __device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf*
       const cf wd = cmul(w, d);
       if (ok) {
         // -i * wd = (wd.y, -wd.x);  for NC-k: conj(sm) and -i * conj(wd) = (-wd.y, -wd.x)
+        if constexpr (PLAIN) {
+          out[(long long)k * out_ok + tt] = make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));
+          out[(long long)(NC - k) * out_ok + tt] = make_float2(0.5f * (sm.x - wd.y), 0.5f * (-sm.y - wd.x));
+        } else {
         store_stream(&out[(long long)k * out_ok + tt], make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x)));
         store_stream(&out[(long long)(NC - k) * out_ok + tt], make_float2(0.5f * (sm.x - wd.y), 0.5f * (-sm.y - wd.x)));
+        }
+      }
+    }
+  }
+}
+
+// The same for 8-line tiles with 16-byte stores: a thread owns the lines (tt, tt + 1) of a mode pair, so a 64-byte output
+// segment leaves as four dwordx4 stores instead of eight dwordx2 (half the store instructions of the pencil kernel's epilogue).
+typedef float vps_f4 __attribute__((ext_vector_type(4)));
+template <int NC, int T, int NT, bool PLAIN = false>
+__device__ __forceinline__ void r2c_store_tile16(const cf* buf, int tid, const cf* __restrict__ tw_r2c, cf* out,
+                                                 long long out_ok, cf* nyq) {
+  static_assert((NC & 1) == 0 && (T & 1) == 0, "pairs of lines");
+  constexpr int H = T / 2;
+  constexpr int ITEMS = (NC / 2) * H;
+  static_assert(ITEMS % NT == 0, "whole rounds");
+#pragma unroll 4
+  for (int i = 0; i < ITEMS / NT; ++i) {
+    const int idx = tid + i * NT;
+    const int tt = (idx % H) * 2, k = idx / H;
+    const cf a0 = buf[tridx<T>(k, tt)], a1 = buf[tridx<T>(k, tt + 1)];
+    if (k == 0) {
+      *reinterpret_cast<vps_f4*>(&out[tt]) = vps_f4{a0.x + a0.y, 0.f, a1.x + a1.y, 0.f};
+      *reinterpret_cast<vps_f4*>(&nyq[tt]) = vps_f4{a0.x - a0.y, 0.f, a1.x - a1.y, 0.f};
+      const cf h0 = buf[tridx<T>(NC / 2, tt)], h1 = buf[tridx<T>(NC / 2, tt + 1)];
+      *reinterpret_cast<vps_f4*>(&out[(long long)(NC / 2) * out_ok + tt]) = vps_f4{h0.x, -h0.y, h1.x, -h1.y};
+    } else {
+      const cf n0 = buf[tridx<T>(NC - k, tt)], n1 = buf[tridx<T>(NC - k, tt + 1)];
+      const cf w = tw_r2c[k];
+      const cf s0 = make_float2(a0.x + n0.x, a0.y - n0.y), d0 = make_float2(a0.x - n0.x, a0.y + n0.y);
+      const cf s1 = make_float2(a1.x + n1.x, a1.y - n1.y), d1 = make_float2(a1.x - n1.x, a1.y + n1.y);
+      const cf w0 = cmul(w, d0), w1 = cmul(w, d1);
+      const vps_f4 lo = {0.5f * (s0.x + w0.y), 0.5f * (s0.y - w0.x), 0.5f * (s1.x + w1.y), 0.5f * (s1.y - w1.x)};
+      const vps_f4 hi = {0.5f * (s0.x - w0.y), 0.5f * (-s0.y - w0.x), 0.5f * (s1.x - w1.y), 0.5f * (-s1.y - w1.x)};
+      if constexpr (PLAIN) {
+        *reinterpret_cast<vps_f4*>(&out[(long long)k * out_ok + tt]) = lo;
+        *reinterpret_cast<vps_f4*>(&out[(long long)(NC - k) * out_ok + tt]) = hi;
+      } else {
+        __builtin_nontemporal_store(lo, reinterpret_cast<vps_f4*>(&out[(long long)k * out_ok + tt]));
+        __builtin_nontemporal_store(hi, reinterpret_cast<vps_f4*>(&out[(long long)(NC - k) * out_ok + tt]));
       }
     }
   }
@@ -910,6 +954,12 @@ constexpr int pencil_lanes() {
   return (NC >= 1024 && VPS_PENCIL_HALF_LANES_LONG) ? PlanInfo<NC>::L / 2 : PlanInfo<NC>::L;
 }
 
+#ifndef VPS_ST16_MODE
+#define VPS_ST16_MODE 0
+#endif
+#ifndef VPS_PLAIN_MODE
+#define VPS_PLAIN_MODE 0
+#endif
 template <int NC, int TP, bool ENERGY = false>
 __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()) pencil_fft_z_kernel(const PencilParams p) {
   typedef PlanInfo<NC> PI;
@@ -1113,7 +1163,15 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
     const int oc = ENERGY ? 0 : c;
     cf* out = p.out[oc] + (long long)x * NC * N + y0;
     cf* nyq = p.nyq[oc] + (long long)x * N + y0;
-    r2c_store_tile<NC, TP, NT, false>(buf, tidc, p.tw_r2c, out, N, nyq, TP);
+    // epilogue flavour of 8-line pencils (64-byte output segments): 16-byte stores and / or plain instead of streaming stores,
+    // per kernel (bit 0: vector launches, bit 1: the energy launch) -- measured at C4, DESIGN.md section 7
+    constexpr int WHO = ENERGY ? 2 : 1;
+    constexpr bool ST16 = (VPS_ST16_MODE & WHO) && TP == 8 && (NC & 1) == 0 && ((NC / 2) * (TP / 2)) % NT == 0;
+    constexpr bool PLAIN = (VPS_PLAIN_MODE & WHO) && TP < 16;
+    if constexpr (ST16)
+      r2c_store_tile16<NC, TP, NT, PLAIN>(buf, tidc, p.tw_r2c, out, N, nyq);
+    else
+      r2c_store_tile<NC, TP, NT, false, PLAIN>(buf, tidc, p.tw_r2c, out, N, nyq, TP);
   }
 }
 
@@ -1424,6 +1482,17 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pas
         int lc = l;
         asm volatile("" : "+v"(lc));
         lc = (L & (L - 1)) == 0 ? (lc & (L - 1)) : lc % L;   // give the value range back to the compiler (address folding needs it)
+#ifdef VPS_X_PREFETCH
+        // second register set: the NEXT line set (next component of this tile, or the first of the next tile) is requested
+        // before this one is transformed, so that its loads fly behind the whole transform
+        cf w[RL];
+        if (c + 1 < p.ncomp) {
+          load_line(w, c + 1, lc);
+        } else if (tile + gridDim.x < ntiles) {
+          locate_line(tile + gridDim.x);
+          load_line(w, 0, lc);
+        }
+#endif
         exchange_sync<WSYNC>();  // previous readers are done with the line buffers
         fft_from_regs<NC, WSYNC>(v, line, tw, lc);
 #pragma unroll
@@ -1431,6 +1500,11 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pas
           const float a = v[i].x * v[i].x + v[i].y * v[i].y;
           pacc[i] = (c == 0) ? a : pacc[i] + a;
         }
+#ifdef VPS_X_PREFETCH
+#pragma unroll
+        for (int i = 0; i < RL; ++i) v[i] = w[i];
+        continue;
+#endif
         // (Requesting the next line BEFORE this transform -- a second register set, affordable at 2048 where LDS limits
         // the kernel to two waves per SIMD -- was measured at 2048^3: 73.2 against 72.5 ms per step; twiddles and shell
         // thresholds left in L2 instead of LDS (46 KB: three workgroups per CU instead of two): 73 ms.  Not kept.)
@@ -1731,6 +1805,10 @@ int launch_x(vps_ctx* ctx, const XParams& p_in, bool fast = false) {
   long long per_cu = (long long)(ctx->lds_per_cu / (lds ? lds : 1));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
+  {
+    const long long want = (long long)vps_option("x_wg_per_cu", 0);
+    if (want >= 1 && want < per_cu) per_cu = want;
+  }
   long long grid = (long long)ctx->num_cu * per_cu;
   if (grid > ntiles) grid = ntiles;
   if (grid < 1) return VPS_OK;

@@ -79,13 +79,23 @@ def load_snapshot(file, Lbox=1.0, remove_bulk_velocity=True, shift_to_origin=Tru
     return gp
 
 
+try:   # a 10 GB/s hash where the host has it; zlib (stdlib) otherwise
+    from xxhash import xxh3_128_digest as _digest
+except ImportError:  # pragma: no cover
+    import zlib
+
+    def _digest(buf):
+        return zlib.crc32(buf).to_bytes(4, "little") + zlib.adler32(buf).to_bytes(4, "little")
+
+
 def _fingerprint(a):
-    """Cheap identity of a host array's CONTENT: where it lives, its layout, and a strided sample of its values -- enough
-    to notice an in-place edit of the whole array (shift, rescale) between two device calls."""
+    """Identity of a host array's CONTENT: its layout and a hash of EVERY byte, so that no in-place edit -- one particle's
+    density, one column of the velocities, a few rows -- can go unnoticed between two device calls.  (A strided sample of
+    the values, which this used to be, misses exactly those.)  Hashing runs at memory speed, several times faster than the
+    dtype conversion + pageable host-to-device copy it decides about."""
     a = np.asarray(a)
-    flat = a.reshape(-1)
-    step = max(1, flat.size // 257)
-    return (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str, flat[::step][:257].tobytes())
+    c = a if a.flags.c_contiguous else np.ascontiguousarray(a)
+    return (a.shape, a.dtype.str, _digest(memoryview(c).cast("B")))
 
 
 class GasParticles:
@@ -94,7 +104,7 @@ class GasParticles:
     The particle arrays are numpy arrays, as in the reference; their device copies (positions as given, float32
     velocities and densities, the [rho v, rho] payload) are made on first use and KEPT: a second `ann_interp_to_field` /
     `deposit_to_field(N).spctrm(q)` on the same object uploads nothing.  A copy is dropped when its attribute is assigned
-    again or when the array's content fingerprint changed (an in-place edit); `invalidate_device()` drops them all."""
+    again or when the hash of the array's bytes changed (any in-place edit); `invalidate_device()` drops them all."""
 
     _DEVICE_ATTRS = {"pos": ("pos",), "mass": ("mass",), "density": ("rho", "payload"), "velocity": ("vel", "payload"),
                      "v": ("vel", "payload")}
@@ -154,8 +164,11 @@ class GasParticles:
                 or not pos.flags.writeable or not v.flags.writeable:
             return False
         k = _kernels()
-        dpos, dvel = self._device_pos(k), self._device_vel(k)
-        k.preprocess(dpos, dvel if bulk else None, self._device_mass(k) if bulk else None, shift, bulk)
+        # fresh tensors: a lazy BoxField made earlier (deposit_to_field / ann_interp_to_field) holds the resident copies it
+        # was made from and must keep seeing the particles as they were then, like the reference's eager field would
+        dpos = self._device_pos(k).clone() if shift else self._device_pos(k)
+        dvel = self._device_vel(k).clone() if bulk else None
+        k.preprocess(dpos, dvel, self._device_mass(k) if bulk else None, shift, bulk)
         if shift:
             pos[...] = dpos.cpu().numpy()
             self._devcache["pos"] = ((_fingerprint(self.pos),), dpos)

@@ -779,7 +779,7 @@ def test_particles_stay_resident_across_library_calls(K):
     # same numbers as a fresh object built from the preprocessed host arrays
     sp1b = interp.GasParticles(gp.pos.copy(), mass, dens, gp.v.copy(), L).deposit_to_field(N).spctrm("velocity")
     assert np.array_equal(sp1.Nsample, sp1b.Nsample) and np.allclose(sp1.Psum, sp1b.Psum, rtol=1e-6)
-    # an in-place edit is noticed (fingerprint), an assignment drops the copy
+    # an in-place edit is noticed (hash of every byte), an assignment drops the copy
     n2 = K.h2d_copies
     gp.v[:, 0] *= 2.0
     sp4 = gp.deposit_to_field(N).spctrm("velocity")
@@ -787,6 +787,57 @@ def test_particles_stay_resident_across_library_calls(K):
     gp.density = dens * 2
     gp.deposit_to_field(N).spctrm("momentum")
     assert K.h2d_copies == n2 + 2
+    # SPARSE in-place edits (the reference edits these arrays in place, interp.py:400-402): one column that a strided
+    # sample of an (n, 3) array never visits, a short row range, ONE particle's density, one coordinate -- each is seen as
+    # exactly one upload of the edited array and a different spectrum
+    last = sp4
+    for edit, quantity in ((lambda: gp.v.__setitem__((slice(None), 1), gp.v[:, 1] * 2.0), "velocity"),
+                           (lambda: gp.v.__setitem__(slice(5, 50), 0.0), "velocity"),
+                           (lambda: gp.density.__setitem__(12345, gp.density[12345] * 50.0), "momentum"),
+                           (lambda: gp.pos.__setitem__((777, 2), 0.5 * L - gp.pos[777, 2] * 0.5), "velocity")):
+        ref_sp = gp.deposit_to_field(N).spctrm(quantity)
+        n3 = K.h2d_copies
+        edit()
+        sp = gp.deposit_to_field(N).spctrm(quantity)
+        assert K.h2d_copies == n3 + 1, "a sparse in-place edit must cost exactly one upload"
+        assert not np.array_equal(sp.Psum, ref_sp.Psum), "the edit must reach the device"
+        fresh = interp.GasParticles(gp.pos.copy(), mass, gp.density.copy(), gp.v.copy(), L).deposit_to_field(N).spctrm(quantity)
+        assert np.array_equal(sp.Nsample, fresh.Nsample) and np.allclose(sp.Psum, fresh.Psum, rtol=1e-6)
+    # a lazy field made BEFORE a preprocessing call keeps the particles as they were then (the reference's field is eager)
+    gp2 = interp.GasParticles(pos.copy(), mass, dens, vel.copy(), L)
+    before = interp.GasParticles(pos.copy(), mass, dens, vel.copy(), L).deposit_to_field(N).spctrm("velocity")
+    box_lazy = gp2.deposit_to_field(N)
+    gp2.remove_bulk_velocity()
+    gp2.shift_to_origin()
+    sp_lazy = box_lazy.spctrm("velocity")
+    assert np.array_equal(sp_lazy.Nsample, before.Nsample) and np.allclose(sp_lazy.Psum, before.Psum, rtol=1e-6)
+
+
+def test_load_snapshot_npz_to_spectrum_against_oracle(K, tmp_path):
+    """load_snapshot (reference interp.py:84-131; `.npz` branch, h5py is absent here) -> vps_preprocess on the resident copies ->
+    deposit_to_field(N).spctrm(q): against the oracle run on the oracle's own preprocessing of the same file contents."""
+    from vpower import interp
+    rng = np.random.default_rng(21)
+    n, N, L = 60_000, 32, 1.5
+    c = (0.2 + rng.random((n, 3)) * (L - 0.2) * 0.999).astype(np.float32)
+    m = np.ones(n, dtype=np.float32)
+    d = np.exp(0.4 * rng.standard_normal(n)).astype(np.float32)
+    v = (rng.standard_normal((n, 3)) + np.array([1.0, 0.0, -2.0])).astype(np.float32)
+    f = tmp_path / "snap.npz"
+    np.savez(f, Coordinates=c, Masses=m, Density=d, Velocities=v)
+    n0 = K.h2d_copies
+    gp = interp.load_snapshot(str(f), Lbox=L)
+    ref_pos, ref_vel = orc.preprocess_script(c, m, v)
+    assert np.array_equal(gp.pos, ref_pos) and np.allclose(gp.v, ref_vel, rtol=0, atol=2e-6)
+    for q in ("velocity", "energy"):
+        sp = gp.deposit_to_field(N).spctrm(q)
+        grid = orc.deposit_to_grid_fast(orc.density_velocity_vector(ref_vel.astype(np.float64), d.astype(np.float64)),
+                                        ref_pos, N, L)
+        vv, mm = orc.vm_from_vec_grid(grid, L / N, zero_empty=True)
+        ref = orc.box_spctrm(vv[..., 0], vv[..., 1], vv[..., 2], mm, L / N, quantity=q)
+        assert np.array_equal(sp.Nsample, ref[:, 3])
+        assert np.allclose(sp.Psum, ref[:, 2], rtol=PSUM_RTOL, atol=0)
+    assert K.h2d_copies - n0 == 4      # positions, velocities, masses (bulk velocity), densities: once each
 
 
 @pytest.mark.parametrize("N,quantity,flags", [(128, "velocity", 0), (256, "momentum", 0), (128, "momentum", 1)])

@@ -236,3 +236,77 @@ def test_bench_starts_its_own_ranks(tmp_path):
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=env2, capture_output=True, text=True, timeout=120)
     assert r2.returncode == 2
+
+
+@pytest.mark.parametrize("n", [200_000, 1_000_000])
+def test_residency_fingerprint_sees_sparse_in_place_edits(n):
+    """GasParticles keeps device copies keyed by a hash of EVERY byte of the host array (vpower/interp.py `_fingerprint`): the
+    edits a 257-value strided sample of an (n, 3) array misses -- a whole column, a short row range, one value -- all change it
+    (the reference edits these arrays in place, interp.py:400-402)."""
+    from vpower import interp
+    rng = np.random.default_rng(11)
+    v = rng.standard_normal((n, 3)).astype(np.float32)
+    rho = np.exp(rng.standard_normal(n)).astype(np.float32)
+    f0 = interp._fingerprint(v)
+    assert interp._fingerprint(v) == f0 and interp._fingerprint(v.copy()) == f0
+    for edit in (lambda a: a.__setitem__((slice(None), 1), a[:, 1] * 2), lambda a: a.__setitem__((slice(None), 2), a[:, 2] + 1),
+                 lambda a: a.__setitem__(slice(5, 50), 0.0), lambda a: a.__setitem__((n - 1, 0), 3.0)):
+        w = v.copy()
+        edit(w)
+        assert interp._fingerprint(w) != f0
+    r0 = interp._fingerprint(rho)
+    rho[n // 3] *= 2
+    assert interp._fingerprint(rho) != r0
+    # a non-contiguous view hashes what it shows
+    assert interp._fingerprint(v[:, 1]) == interp._fingerprint(np.ascontiguousarray(v[:, 1]))
+
+
+@pytest.mark.parametrize("bulk,shift", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_load_snapshot_npz_branch_matches_oracle_preprocessing(tmp_path, bulk, shift, dtype):
+    """load_snapshot (reference interp.py:84-131) through its `.npz` branch -- h5py is not on this host, the four GIZMO keys
+    are the same -- with every combination of the two preprocessing flags, against the oracle's restatement of
+    interp.py:169-182 / script:280-291.  Without a GPU the numpy route runs: the same float arithmetic, so equality is exact."""
+    from vpower import interp
+    rng = np.random.default_rng(5)
+    n, L = 5000, 3.0
+    c = (0.4 + rng.random((n, 3)) * (L - 0.4)).astype(dtype)
+    m = (0.5 + rng.random(n)).astype(dtype)
+    d = np.exp(0.3 * rng.standard_normal(n)).astype(dtype)
+    v = (rng.standard_normal((n, 3)) + np.array([2.0, -1.0, 0.5])).astype(dtype)
+    f = tmp_path / "snap.npz"
+    np.savez(f, Coordinates=c, Masses=m, Density=d, Velocities=v)
+    gp = interp.load_snapshot(str(f), Lbox=L, remove_bulk_velocity=bulk, shift_to_origin=shift)
+    assert isinstance(gp, interp.GasParticles) and len(gp) == n and gp.Lbox == L
+    ref_pos, ref_vel = orc.preprocess_script(c, m, v, remove_bulk=bulk)
+    if not shift:
+        ref_pos = c
+    import torch
+    exact = not torch.cuda.is_available()      # on a GPU box the float32 arrays go through vps_preprocess (float64 bulk sums)
+    if exact or dtype == np.float64:
+        assert np.array_equal(gp.pos, ref_pos) and np.array_equal(gp.v, ref_vel)
+    else:
+        assert np.array_equal(gp.pos, ref_pos) and np.allclose(gp.v, ref_vel, rtol=0, atol=2e-6)
+    assert np.array_equal(gp.mass, m) and np.array_equal(gp.density, d)
+    assert gp.v is gp.velocity or np.shares_memory(gp.v, gp.velocity)     # one array under both names, as in the reference
+    assert np.allclose(gp.r, ((3 * m / d) / (4 * np.pi)) ** (1 / 3))
+    with pytest.raises(Exception):
+        interp.load_snapshot(str(tmp_path / "missing.hdf5"))
+
+
+def test_exchange_group_is_closed_on_every_error_path(tmp_path):
+    """csrc/comm_group.h -- one chunk of the slab exchange (what replaces the reference's comm.allgather calls,
+    scripts/parallel_optimized.py:365-368) as ONE RCCL group -- driven by a recording stand-in for the RCCL table on the host:
+    the n-th send / receive / GroupStart / GroupEnd fails, the group is closed on every path, nothing is issued after the first
+    failure and the first failure is what the caller sees (tests/native/test_comm_group.cpp)."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        pytest.skip("no host C++ compiler")
+    exe = str(tmp_path / "test_comm_group")
+    src = os.path.join(ROOT, "tests", "native", "test_comm_group.cpp")
+    inc = os.path.join(ROOT, "large-velocity-power-spectrum_amd", "csrc")
+    subprocess.run([cxx, "-std=c++17", "-O1", "-Wall", "-Werror", "-I", inc, src, "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr

@@ -5,6 +5,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "large-velocity-
 import numpy as np, torch
 from vpower import device
 K = device.default_kernels()
+if os.environ.get("VPS_X_WG"):      # occupancy experiment: persistent workgroups per CU
+    K.lib.vps_set_option(b"x_wg_per_cu", float(os.environ["VPS_X_WG"]))
 N = int(sys.argv[1]); ncomp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 pipe = device.PowerPipeline(N, 1.0, kernels=K, comm=device.SlabComm(enabled=False))
 pipe.prepare()
