@@ -63,10 +63,10 @@ def parse_args(argv=None):
     ap.add_argument("--unfused", action="store_true", help="NGP route: separate deposit and z-pass kernels (grid through HBM)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the roofline")
     ap.add_argument("--decomposition", choices=("auto", "slab", "fields"), default="auto",
-                    help="several GPUs: 'slab' = 1-D x-slabs with one all-to-all per field (any grid; the only choice beyond one "
-                         "GPU's memory: C5); 'fields' = every rank transforms whole grids of its share of the step's scalar fields, "
-                         "only shell tables cross the node (grids that fit one GPU); 'auto' = fields where possible, else slab.  "
-                         "The decomposition that is not chosen is timed as well and reported under `alternative`")
+                    help="several GPUs: 'slab' = 1-D x-slabs with one all-to-all per field -- what BASELINE.json's configs and the "
+                         "north star name, and the only choice beyond one GPU's memory (C5); 'fields' = every rank transforms whole "
+                         "grids of its share of the step's scalar fields, only shell tables cross the node (grids that fit one GPU); "
+                         "'auto' = slab.  Where both are possible the one not chosen is timed as well and reported under `alternative`")
     ap.add_argument("--no-alternative", action="store_true",
                     help="several GPUs: skip the extra timed leg with the other decomposition")
     ap.add_argument("--emulate-ranks", type=int, default=0,
@@ -136,6 +136,39 @@ def baseline_json():
 NCOMP = {"velocity": 3, "momentum": 3, "energy": 1}
 
 
+def kernel_sources_sha16():
+    """Hash of the HIP sources the profiled kernels are built from (csrc/*.hip, *.h)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "large-velocity-power-spectrum_amd", "csrc", "*.hip"))
+                    + glob.glob(os.path.join(ROOT, "large-velocity-power-spectrum_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(cfg, kernel):
+    """(bytes per launch or None, where the figure comes from) for the dominant kernel of `cfg`, from the newest tracked
+    profiles/rNN_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 correction)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    if not files:
+        return None, "no tracked PMC profile"
+    path = files[-1]
+    rel = os.path.relpath(path, ROOT)
+    try:
+        d = json.load(open(path))
+    except Exception as e:
+        return None, "%s unreadable: %s" % (rel, e)
+    sha = d.get("kernel_sources_sha16")
+    if sha is not None and sha != kernel_sources_sha16():
+        return None, "%s is stale: the kernel sources changed after it was taken (not measured in this run)" % rel
+    val = d.get(cfg, {}).get(kernel)
+    return val, "%s (rocprofv3 --pmc passes of an earlier run of this command%s; not measured in this run)" % (
+        rel, "" if sha is not None else ", taken before source hashes were recorded")
+
+
 class Workload:
     """One config's step on the device: particles resident in HBM -> {quantity: (nbins,4) table}.
     The same class runs the timed region, the instrumented steps and the small oracle-checked
@@ -164,16 +197,14 @@ class Workload:
                 # a rank holds the whole (replicated) particle set but sorts only those inside its slab: the workspace is
                 # sized for them (counted once, outside the timed region; 1 % head room for nothing -- the count is exact)
                 self.slab_particles = K.count_in_slab(pos, N, L, self.x0, nx)
-            # Several ranks, several quantities: the quantities are pipelined -- quantity q+1's deposit + z pass is issued while
-            # q's chunks are still crossing the node, q's x passes run after it.  Needs a z image per quantity and two
-            # quantities' send / receive buffers at a time: on from 4 ranks (2 ranks of C4 would need > 288 GB), or
-            # VPS_PIPELINE_QUANTITIES=1 / 0.
-            env = os.environ.get("VPS_PIPELINE_QUANTITIES")
-            self.pipelined = (self.pipe.chunked and len(self.quantities) > 1 and not isinstance(comm, device.LibraryComm)
-                              and all(K.fused_supported(N, device.QUANTITY[q]) for q in self.quantities) and not unfused
-                              and ((comm.world >= 4) if env is None else env == "1"))
+            # Several ranks: the kz chunks of ALL quantities of the step form one bounded pipeline (PowerPipeline.pipelined_quantities:
+            # two chunks in flight) -- quantity q+1's deposit + z pass is issued while q's last chunks are still crossing the node.
+            # One z image (every y pass of q is enqueued before q+1's deposit overwrites it) and two chunks' send / receive buffers,
+            # whatever the rank count.  VPS_PIPELINE_QUANTITIES=0: one quantity after the other, tables in between.
+            self.pipelined = (self.pipe.chunked and not isinstance(comm, device.LibraryComm) and self.fused
+                              and os.environ.get("VPS_PIPELINE_QUANTITIES") != "0")
             if self.pipelined:
-                self.zimg_q = [K.empty((NCOMP[q], K.zimage_elems(N, nx)), torch.complex64) for q in self.quantities]
+                self.zimg = K.empty((maxc, K.zimage_elems(N, nx)), torch.complex64)
                 self.acc_q = [self.pipe.new_accumulators() for _ in self.quantities]
             elif self.fused and self.pipe.chunked:
                 self.zimg = K.empty((maxc, K.zimage_elems(N, nx)), torch.complex64)
@@ -209,7 +240,7 @@ class Workload:
     def describe_path(self):
         if self.route == "ngp":
             if getattr(self, "pipelined", False):
-                return "fused deposit+z pass (pencil buckets); quantities pipelined against each other's exchanges"
+                return "fused deposit+z pass (pencil buckets); kz chunks of all quantities in one pipeline, two in flight"
             if isinstance(self.comm, self.dev.FieldComm):
                 return "fused deposit+z pass (pencil buckets), one scalar field per launch; fields dealt out over the ranks"
             return "fused deposit+z pass (pencil buckets)" if self.fused else "deposit -> grid -> z pass"
@@ -254,7 +285,7 @@ class Workload:
 
             def producer(i, q):
                 def produce():
-                    z = K.deposit_fft_z(self.pos, self.vel, self.rho, N, L, x0, nx, dev.QUANTITY[q], zimg=self.zimg_q[i],
+                    z = K.deposit_fft_z(self.pos, self.vel, self.rho, N, L, x0, nx, dev.QUANTITY[q], zimg=self.zimg[:NCOMP[q]],
                                         reuse_sort=state["token"], slab_particles=self.slab_particles)
                     state["token"] = K.fused_token()
                     return [z[c] for c in range(NCOMP[q])]
@@ -262,7 +293,7 @@ class Workload:
             for ps, ns in self.acc_q:
                 ps.zero_()
                 ns.zero_()
-            # quantity q+1's deposit + z pass + y passes are issued while q's chunks cross the node (PowerPipeline.pipelined_quantities)
+            # one bounded pipeline of kz-chunk jobs over all quantities (PowerPipeline.pipelined_quantities)
             self.pipe.pipelined_quantities([producer(i, q) for i, q in enumerate(self.quantities)], self.acc_q)
             for i, q in enumerate(self.quantities):
                 tab = self.pipe.finish(*self.acc_q[i])
@@ -503,7 +534,48 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     per = {k: np.asarray(K.timing_list(k)) for k in ("fft_z", "fft_y", "fft_x", "deposit", "algebra", "nn_build", "nn_query")}
     K.timing(False)
     nst = max(profile_steps, 1)
-    step_kernel_ms = {k: v[1] / nst for k, v in tim.items() if v[0]}
+    step_kernel_ms = {k: v[1] / nst for k, v in tim.items() if v[0] and not k.startswith("exchange")}
+    # ---- slab exchange: how long it takes and how much of it the step cannot hide (several ranks; max over ranks) ----
+    #   kernel_ms            this rank's kernels per step (HIP events on the library's stream)
+    #   exposed_exchange_ms  per step, the time the compute stream stood still waiting for blocks to arrive, with the step's own
+    #                        overlap (events around every wait of a chunk's x pass on its all-to-all)
+    #   exchange_ms          per step, the exchanges by themselves: torch transport -- one extra step with ONE chunk in flight
+    #                        (nothing overlaps: exchange start -> arrival); library transport -- the grouped send / recv intervals
+    #                        on the library's communication stream (VPS_K_EXCHANGE)
+    exchange = None
+    slab_run = wl.pipe.chunked and (G > 1 or bool(getattr(comm, "force", False)))
+    if slab_run:
+        tsum = lambda name: tim.get(name, (0, 0.0))[1] / nst
+        if isinstance(comm, device.LibraryComm):
+            exchange = {"kernel_ms": sum(step_kernel_ms.values()), "exchange_ms": tsum("exchange"),
+                        "exposed_exchange_ms": tsum("exchange_wait"),
+                        "how": "HIP events inside the library: communication stream around each chunk's ncclSend / ncclRecv group; "
+                               "context stream around each wait of an x pass on its chunk"}
+        else:
+            wl.pipe.instr = []
+            wl.step()
+            exposed, _ = wl.pipe.exchange_times()
+            prev_inflight = os.environ.get("VPS_A2A_INFLIGHT")
+            os.environ["VPS_A2A_INFLIGHT"] = "1"
+            try:
+                wl.pipe.instr = []
+                wl.step()
+                _, span = wl.pipe.exchange_times()
+            finally:
+                wl.pipe.instr = None
+                if prev_inflight is None:
+                    os.environ.pop("VPS_A2A_INFLIGHT", None)
+                else:
+                    os.environ["VPS_A2A_INFLIGHT"] = prev_inflight
+            exchange = {"kernel_ms": sum(step_kernel_ms.values()), "exchange_ms": span, "exposed_exchange_ms": exposed,
+                        "how": "torch events on the compute stream: exposed = around every wait on a chunk's all-to-all in a normal "
+                               "step; exchange = start -> arrival in one extra step with a single chunk in flight"}
+        if world > 1:
+            for key in ("kernel_ms", "exchange_ms", "exposed_exchange_ms"):
+                t = torch.tensor([exchange[key]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                exchange[key] = float(t.item())
+            exchange["over"] = "max over the %d ranks" % world
     # y and x launches come as main launches (whole fields, or kz chunks of them) and small Nyquist-plane launches
     # (one plane against hundreds): the main ones are those within a factor 8 of the longest
     def main_of(v, within=8.0):
@@ -538,14 +610,12 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     fft_bytes = step_bytes["fft_z"] + nfl * (8.0 * nx * N * (NH + 1) * (1.0 + keep) + 8.0 * (nkz * N + nky) * N * keep)
     grid_ms = step_kernel_ms.get("deposit", 0.0) + step_kernel_ms.get("algebra", 0.0) \
         + step_kernel_ms.get("nn_build", 0.0) + step_kernel_ms.get("nn_query", 0.0)
-    traffic = None
-    tr_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-    if os.path.exists(tr_path) and world == 1 and G == 1:
-        try:
-            traffic = json.load(open(tr_path)).get(cfg, {}).get(dom)
-        except Exception:
-            traffic = None
-
+    # HBM traffic of the dominant kernel from the PMC counters: NOT measured in this run (counters need rocprofv3 passes of
+    # their own) but copied from the newest tracked profile -- named in `traffic_source`, and dropped when the kernel sources
+    # have changed since that profile was taken (tools/pmc_summary.py records their hash)
+    traffic, traffic_source = None, None
+    if world == 1 and G == 1:
+        traffic, traffic_source = pmc_traffic(cfg, dom)
     bj = baseline_json()
     idx = int(cfg[1]) - 1
     cfg_text = bj["configs"][idx] if idx < len(bj.get("configs", [])) else cfg
@@ -555,11 +625,18 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
         "config": {"workload": "%s: %s" % (cfg, cfg_text),
                    "deviation": rehearsal or "; ".join(x for x in (
                        ("strong-scaled over %d GPU(s) of one node" % world) if cfg in ("C4", "C5") and world != 8 else None,
-                       ("field-parallel decomposition instead of the slab all-to-all the config names: the grid fits one GPU's HBM, so "
-                        "every rank transforms whole grids and nothing but shell tables crosses xGMI; the slab run of the same step "
-                        "is timed under `alternative` (--decomposition slab makes it the reported one)") if fw > 1 else None) if x) or None,
+                       ("field-parallel decomposition (--decomposition fields) instead of the slab all-to-all the config names: every "
+                        "rank transforms whole grids and nothing but shell tables crosses xGMI; the slab run of the same step is timed "
+                        "under `alternative`") if fw > 1 else None) if x) or None,
                    "grid": N, "particles": Np, "route": route, "quantities": list(quantities),
                    "scalar_fields_per_step": nfields, "path": wl.describe_path(),
+                   "decomposition": ("fields" if fw > 1 else "slab") if (world > 1 or G > 1 or slab_run) else "none (one GPU)",
+                   **({"transport": ("libvps_hip.so: grouped ncclSend / ncclRecv on its own stream (RCCL)" if isinstance(comm, device.LibraryComm)
+                                     else "torch.distributed.all_to_all_single (%s)" % (backend if world > 1 else "emulated, no peers")),
+                       "chunks": nchunks, "chunks_in_flight": (2 if isinstance(comm, device.LibraryComm) else wl.pipe.inflight_max()),
+                       "exchange_row_fraction": exchange_rows, "slab_exchange": exchange,
+                       "ms_per_step_slab": ms_per_step} if slab_run else {}),
+                   **({"ms_per_step_fields": ms_per_step} if fw > 1 else {}),
                    "parallelism": ("x-slab x%d, one message per field and pair of ranks in %d kz chunks (unbinned rows left out, Nyquist rows inside it)"
                                    % (world, nchunks)) if (G == world and world > 1)
                    else ("field-parallel: the step's %d scalar fields dealt out over %d ranks, whole %d^3 grid per GPU, only shell tables cross the node"
@@ -575,7 +652,7 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
                       "frac_of_hbm_peak": fft_bytes / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fft_ms else None},
         "kernel_ms_per_step": step_kernel_ms,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": step_bytes[dom] / launches_per_step[dom],
                      "avg_launch_ms": kms[dom] / launches_per_step[dom],
                      "launches_per_step": launches_per_step[dom]},
@@ -590,6 +667,8 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
     }
     if exchange_rows is not None:
         res["exchange_row_fraction"] = exchange_rows   # rows per kz plane in the exchanged blocks / N
+    if exchange is not None:
+        res["slab_exchange"] = exchange
     finite = all(np.isfinite(t[:, 2]).all() and t[:, 3].sum() > 0 for t in tabs.values())
     if rank == 0 and not os.environ.get("VPS_BENCH_NOCHECK"):      # (timing-only kernel variants produce garbage)
         assert finite, "non-finite shell sums"
@@ -706,7 +785,12 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
                                ("x-slab x%d, one message per field and pair of ranks in %d kz chunks (unbinned rows left out), %s"
                                 % (world, owl.pipe.nchunks, owl.describe_path())),
                 "vs_own_tables": {"nsample_equal": eq, "psum_max_rel": worst},
-                "note": "python bench.py --gpus N --decomposition %s makes this the reported decomposition" % other}
+                "note": "python bench.py --gpus N --decomposition %s makes this the reported decomposition" % other,
+                **({"why": "xGMI is point-to-point: the slab transform sends every field's half spectrum through the links once (at two "
+                           "ranks through ONE link), dealing the scalar fields out sends nbins numbers -- but it stops at 7 fields "
+                           "(C4) and at grids that fit one GPU, and it is not the decomposition BASELINE.json names"}
+                   if other == "fields" else {})}
+            res["config"]["ms_per_step_" + other] = dto / steps * 1e3     # (both decompositions' step times inside `config`)
             if rank == 0 and not os.environ.get("VPS_BENCH_NOCHECK"):
                 assert eq and worst <= PSUM_RTOL, "field-parallel and slab tables differ: %s %.3g" % (eq, worst)
             del otabs
@@ -746,7 +830,7 @@ def cpu_baseline_legs(cfg):
     """The CPU side of the measurement (rank 0, one GPU run only; AFTER every device timing: the threaded leg leaves worker
     pools behind that slow the host's kernel launches).  One core: the oracle at the size of BASELINE config 2 (512^3 --
     SURVEY.md 8d makes it the base from which configs 3-5 are extrapolated; 256^3 for the NN route), at the config's particle
-    density, stage by stage.  All cores: the same on the 256^3 / 128^3 parity sample with the transforms threaded."""
+    density, stage by stage.  All cores (NGP): the same sample through oracle/allcores.py, every stage spread over the cores."""
     from vpower import synth
     from oracle import vps_oracle as orc
     N, Np, off = synth.CONFIGS[cfg]
@@ -769,7 +853,31 @@ def cpu_baseline_legs(cfg):
         "extrapolated_seconds_full_size": t1["total"] * scale,
         "extrapolation": "by the algorithmic-bytes ratio (N/%d)^3 (SURVEY.md 8d); not measured" % Nc,
         "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
-    if route != "script":
+    if route == "ngp":
+        # all host cores, the WHOLE step spread over them the way the reference spreads its work over MPI ranks (every rank a part of
+        # the volume, scripts/parallel_optimized.py:201-491 under `mpiexec -n R`): oracle/allcores.py -- one process per x-slab for
+        # gridding, |F|^2 and both histograms, threaded transforms -- on the SAME sample as the one-core leg.  A child process of its
+        # own: it forks its workers, and they must not inherit this process's GPU state.
+        nthr = min(os.cpu_count() or 1, 128, Nc // 2)
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "allcores.py"), "--grid", str(Nc), "--particles", str(Npc),
+               "--workers", str(nthr), "--quantities", ",".join(quantities), "--flavour", flavour,
+               "--seed", str(synth.BASE_SEED + 200 + off), "--lognormal", str(int(lognormal))]
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+            t2 = json.loads(r.stdout.strip().splitlines()[-1])
+            out["cpu_baseline_allcores"] = {
+                "value": Nc ** 3 * nfields / t2["seconds"], "unit": unit, "cores": nthr, "kind": "port",
+                "sample": "oracle/allcores.py on the one-core leg's sample (%d^3 cells, %d particles): every stage spread over %d worker "
+                          "processes by x-slab (gridding, field algebra, |F|^2, both histograms) + threaded 3-D transforms: %s"
+                          % (Nc, Npc, nthr, ", ".join("%s %.2fs" % kv for kv in t2["stage_seconds"].items())),
+                "seconds": t2["seconds"], "stage_seconds": t2["stage_seconds"],
+                "speedup_over_one_core": t1["total"] / t2["seconds"],
+                "extrapolated_seconds_full_size": t2["seconds"] * scale,
+                "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
+        except Exception as e:      # (the headline must not be lost to the extra CPU leg)
+            out["cpu_baseline_allcores"] = {"skipped": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    elif route != "script":
         Ns, Nps_ = sample_size(route, N, Np)
         pos, vel, _, dens = synth.particles(synth.BASE_SEED + 100 + off, Nps_, L, lognormal)
         nthr = os.cpu_count() or 1
@@ -781,7 +889,7 @@ def cpu_baseline_legs(cfg):
         out["cpu_baseline_allcores"] = {
             "value": Ns ** 3 * nfields / t2["total"], "unit": unit, "cores": nthr, "kind": "port",
             "sample": "the %d^3 parity sample (%d particles); the 3-D transforms threaded over %d cores (scipy.fft workers), "
-                      "gridding and histograms remain single-threaded numpy: %s"
+                      "the kd-tree search and histograms remain single-threaded numpy: %s"
                       % (Ns, Nps_, nthr, ", ".join("%s %.2fs" % kv for kv in t2.items())),
             "seconds": t2["total"], "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
     return out
@@ -821,11 +929,9 @@ def main(argv=None):
     comm = device.SlabComm()
     decomposition = args.decomposition
     if decomposition == "auto":
-        # point-to-point xGMI: whole grids per GPU and no exchange wherever 288 GB allow it
-        N_ = int(os.environ.get("VPS_BENCH_GRID", synth.CONFIGS[args.config][0])) if args.config in synth.CONFIGS else 0
-        decomposition = "fields" if (world > 1 and args.config in synth.CONFIGS
-                                     and fields_possible(K, N_, synth.WORKLOADS[args.config][0], synth.WORKLOADS[args.config][1],
-                                                         args.unfused)) else "slab"
+        # `value` is the decomposition the metric names (BASELINE.json config 4 / 5: "slab all-to-all"); the field-parallel
+        # split -- the better fit for point-to-point xGMI while a grid fits one GPU, DESIGN.md section 4 -- is the `alternative`
+        decomposition = "slab"
     if decomposition == "fields" and world > 1:
         if args.decomposition == "fields" and args.config in synth.CONFIGS and not fields_possible(
                 K, int(os.environ.get("VPS_BENCH_GRID", synth.CONFIGS[args.config][0])), synth.WORKLOADS[args.config][0],
@@ -833,7 +939,9 @@ def main(argv=None):
             raise SystemExit("--decomposition fields: %s does not fit -- every rank would hold whole grids (fused NGP path, about "
                              "26 N^3 bytes of one GPU's HBM); use --decomposition slab" % args.config)
         comm = device.FieldComm()
-    elif os.environ.get("VPS_BENCH_TRANSPORT") == "library" and world > 1 and backend == "nccl":
+    elif os.environ.get("VPS_BENCH_TRANSPORT") == "library" and ((world > 1 and backend == "nccl")
+                                                                   or (world == 1 and os.environ.get("VPS_FORCE_COLLECTIVES") == "1")):
+        # (one rank with VPS_FORCE_COLLECTIVES=1: the library's chunk pipeline and RCCL plumbing on a single GPU -- a rehearsal)
         # the exchange inside libvps_hip.so (vps_spectrum_zimages: RCCL send / recv groups on the library's own stream)
         # instead of torch.distributed.all_to_all_single; torch only moves the 128-byte id and times the run
         comm = device.LibraryComm(K)

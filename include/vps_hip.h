@@ -65,7 +65,8 @@ int vps_destroy(vps_ctx* ctx);
 const char* vps_last_error(const vps_ctx* ctx);   /* ctx may be NULL: global slot */
 int vps_set_stream(vps_ctx* ctx, void* hip_stream);
 int vps_sync(vps_ctx* ctx);
-int vps_version(void);                            /* ABI version, currently 4       */
+#define VPS_ABI_VERSION 5
+int vps_version(void);                            /* ABI version (VPS_ABI_VERSION)  */
 /* Tuning / test switches, process-wide.  The library never reads the environment: a stray variable in a user's job cannot
  * change a code path; the host sets what it wants explicitly (vpower/_ffi.py maps VPS_OPT_<NAME> variables once, at load,
  * and lists them in _ffi.OPTIONS).  Names: no_fast_binning, no_pair_binning, nn_query_centric, nn_column, nn_build_atomic, nn_kappa, nn_stats,
@@ -76,6 +77,11 @@ double vps_get_option(const char* name, double dflt);
 /* device facts for the host side: out[0]=CUs, out[1]=LDS bytes/CU, out[2]=wave size,
  * out[3]=HBM bytes total (MiB) */
 int vps_device_info(vps_ctx* ctx, int64_t out[4]);
+/* how the binning x pass will decide shells for the tables of the last vps_set_binning, under the current options:
+ * 0 = general monotone shell walk; 1 = mirrored kx, float64 k^2 sums against float64 thresholds; 2 = mirrored kx, INTEGER
+ * ix^2 + iy^2 + iz^2 against integer thresholds (exactly the same shells: chosen only where vps_set_binning has checked
+ * that no threshold lies on an integer multiple of k2[1]); negative: no tables set */
+int vps_binning_mode(vps_ctx* ctx);
 
 /* ---- memory helpers (so the library is usable without torch) ------------ */
 int vps_malloc(vps_ctx* ctx, void** dev, size_t bytes);
@@ -91,7 +97,11 @@ int vps_memcpy_d2h(vps_ctx* ctx, void* host, const void* dev, size_t bytes); /* 
 enum vps_kernel_kind {
   VPS_K_DEPOSIT = 0, VPS_K_ALGEBRA = 1, VPS_K_FFT_Z = 2, VPS_K_FFT_Y = 3,
   VPS_K_FFT_X = 4, VPS_K_NN_BUILD = 5, VPS_K_NN_QUERY = 6, VPS_K_MISC = 7,
-  VPS_K_COUNT = 8
+  /* exchange inside the library (vps_spectrum_zimages): one interval per kz chunk each --
+   * EXCHANGE: the grouped ncclSend / ncclRecv of the chunk, on the communication stream;
+   * EXCHANGE_WAIT: how long the context's stream stood still for it ahead of the chunk's x pass (the EXPOSED part) */
+  VPS_K_EXCHANGE = 8, VPS_K_EXCHANGE_WAIT = 9,
+  VPS_K_COUNT = 10
 };
 int vps_timing_enable(vps_ctx* ctx, int on);
 int vps_timing_reset(vps_ctx* ctx);

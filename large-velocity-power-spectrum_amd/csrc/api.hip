@@ -24,7 +24,7 @@ int vps_fail(vps_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
-vps_launch_timer::vps_launch_timer(vps_ctx* c, int kind) : ctx(c) {
+vps_launch_timer::vps_launch_timer(vps_ctx* c, int kind, hipStream_t on) : ctx(c), stream(on ? on : c->stream) {
   if (!ctx->timing) return;
   vps_timed_launch tl;
   tl.kind = kind;
@@ -39,13 +39,13 @@ vps_launch_timer::vps_launch_timer(vps_ctx* c, int kind) : ctx(c) {
   }
   tl.start = ev[0];
   tl.stop = ev[1];
-  (void)hipEventRecord(tl.start, ctx->stream);
+  (void)hipEventRecord(tl.start, stream);
   ctx->launches.push_back(tl);
   idx = (int)ctx->launches.size() - 1;
 }
 
 vps_launch_timer::~vps_launch_timer() {
-  if (idx >= 0) (void)hipEventRecord(ctx->launches[idx].stop, ctx->stream);
+  if (idx >= 0) (void)hipEventRecord(ctx->launches[idx].stop, stream);
 }
 
 // ---- options ---------------------------------------------------------------------------------------------------------------
@@ -61,6 +61,7 @@ static const char* const k_option_names[] = {
     "sort_staged",        // 0: level-1 records scattered directly instead of LDS-staged runs (tests)
     "sort_atomic",        // 1: one returning global atomic per particle instead of the two-level sort (tests)
     "nn_ablate",          // timing-only builds (-DVPS_TIMING_VARIANTS): ignored otherwise
+    "no_int_binning",     // 1: the mirrored-kx x pass compares float64 k^2 sums even where integer shells are exact (tests)
     "x_wg_per_cu",        // persistent x pass: workgroups per CU (tuning / occupancy experiments; default: what LDS admits)
     "comm_fail_send",     // n >= 1: the n-th ncclSend from now on fails without being issued (error-path tests; clears itself)
 };
@@ -81,7 +82,7 @@ double vps_option(const char* name, double dflt) {
 
 extern "C" {
 
-int vps_version(void) { return 4; }
+int vps_version(void) { return VPS_ABI_VERSION; }
 
 int vps_set_option(const char* name, double value) {
   if (!name) return vps_fail(nullptr, VPS_ERR_ARG, "vps_set_option: null name");
@@ -130,6 +131,7 @@ int vps_destroy(vps_ctx* ctx) {
   vps_fft_free_tables(ctx);
   if (ctx->d_k2) (void)hipFree(ctx->d_k2);
   if (ctx->d_thr) (void)hipFree(ctx->d_thr);
+  if (ctx->d_nthr) (void)hipFree(ctx->d_nthr);
   if (ctx->d_axes) (void)hipFree(ctx->d_axes);
   if (ctx->d_xpart) (void)hipFree(ctx->d_xpart);
   if (ctx->d_win) (void)hipFree(ctx->d_win);
@@ -312,6 +314,37 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
     VPS_HIP_CHECK(ctx, hipMemcpy(ctx->d_kcut, kcut.data(), sizeof(int) * kcut.size(), hipMemcpyHostToDevice));
     ctx->h_kcut = kcut;
   }
+  // integer shells: exact where k2[i] = i^2 k2[1] (to float64 rounding) and no threshold comes within 1e-9 (relative) of an
+  // integer multiple of k2[1] -- a mode's s = (kx^2 + ky^2) + kz^2 deviates from k2[1] n by a few 1e-16 n, so every mode of an
+  // integer n then falls on the same side of every threshold, whatever its float64 rounding
+  if (ctx->d_nthr) VPS_HIP_CHECK(ctx, hipFree(ctx->d_nthr));
+  ctx->d_nthr = nullptr;
+  ctx->bin_int = false;
+  if (fast && N >= 4 && N <= 32768 && k2_axis_host[1] > 0.0) {
+    const double c2 = k2_axis_host[1];
+    bool ok = k2_axis_host[0] == 0.0;
+    for (int i = 1; ok && i <= N / 2; ++i) ok = fabs(k2_axis_host[i] - (double)i * (double)i * c2) <= 1e-12 * (double)i * (double)i * c2;
+    std::vector<unsigned> nthr(nbins + 1);
+    for (int b = 0; ok && b <= nbins; ++b) {
+      const double q = thr_host[b] / c2;
+      if (!(q == q) || q >= 4.0e9) {
+        ok = false;
+      } else if (q <= 0.0) {
+        nthr[b] = 0u;
+      } else {
+        const double r = nearbyint(q);
+        if (fabs(q - r) <= 1e-9 * (q > 1.0 ? q : 1.0)) ok = false;   // a threshold (numerically) ON an integer: rounding decides
+        nthr[b] = (unsigned)ceil(q);
+      }
+    }
+    if (ok) {
+      VPS_HIP_CHECK(ctx, hipMalloc(&ctx->d_nthr, sizeof(unsigned) * (nbins + 1)));
+      VPS_HIP_CHECK(ctx, hipMemcpy(ctx->d_nthr, nthr.data(), sizeof(unsigned) * (nbins + 1), hipMemcpyHostToDevice));
+      ctx->bin_int = true;
+      ctx->bin_nmax = nthr[nbins];
+      ctx->bin_kf = (float)sqrt(c2);
+    }
+  }
   ctx->h_k2.assign(k2_axis_host, k2_axis_host + N);
   ctx->h_thr.assign(thr_host, thr_host + nbins + 1);
   ctx->bin_fast = fast;
@@ -320,6 +353,13 @@ int vps_set_binning(vps_ctx* ctx, int N, const double* k2_axis_host, const doubl
   ctx->edge0 = edge0;
   ctx->inv_spacing = inv_spacing;
   return VPS_OK;
+}
+
+int vps_binning_mode(vps_ctx* ctx) {
+  VPS_ENTER(ctx);
+  if (!ctx->d_k2) return -1;
+  if (!ctx->bin_fast) return 0;
+  return (ctx->bin_int && ctx->d_nthr && vps_option("no_int_binning", 0) == 0) ? 2 : 1;
 }
 
 int vps_set_bin_only(vps_ctx* ctx, int on) {

@@ -259,7 +259,11 @@ int vps_spectrum_zimages(vps_ctx* ctx, int N, int nx, const void* const* zimg_de
     if (c >= 2) VPS_HIP_CHECK(ctx, hipStreamWaitEvent(cm->stream, cm->ev_x[c - 2], 0));
     RcclGroupApi g{api, cm->comm, cm->stream};
     const char* what = nullptr;
-    const ncclResult_t nr = vps_exchange_chunk_group(g, sendp[s], recvp[s], ncomp, G, (size_t)blk[c], (size_t)2, &what);
+    ncclResult_t nr;
+    {
+      vps_launch_timer tm(ctx, VPS_K_EXCHANGE, cm->stream);
+      nr = vps_exchange_chunk_group(g, sendp[s], recvp[s], ncomp, G, (size_t)blk[c], (size_t)2, &what);
+    }
     if (nr != ncclSuccess)
       return vps_fail(ctx, VPS_ERR_HIP, "vps_spectrum_zimages: %s failed in chunk %d: %s (group closed)", what ? what : "RCCL",
                       c, api.GetErrorString(nr));
@@ -270,7 +274,10 @@ int vps_spectrum_zimages(vps_ctx* ctx, int N, int nx, const void* const* zimg_de
   for (int c = 0; c < nchunks && !rc; ++c) {
     // chunk c + 1 is transformed while c travels, and travels while c is binned
     if (c + 1 < nchunks && (rc = start_chunk(c + 1))) break;
-    VPS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, cm->ev_a[c], 0));
+    {
+      vps_launch_timer tm(ctx, VPS_K_EXCHANGE_WAIT);   // (two events around a wait: the time the stream stood still)
+      VPS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, cm->ev_a[c], 0));
+    }
     const void* ins[3];
     for (int k = 0; k < ncomp; ++k) ins[k] = recvp[c & 1][k];
     rc = vps_fft_x_bin_chunk(ctx, N, nx, G, nchunks, c, r, packed, ins, ncomp, count, psum_dev, nsample_dev);

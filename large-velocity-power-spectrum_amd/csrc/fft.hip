@@ -404,6 +404,58 @@ __device__ __forceinline__ void twiddle_butterfly(cf (&v)[RL], const cf* tw, int
   }
 }
 
+// The same with the stage's twiddles in registers, loaded once per kernel (load_stage_twiddles): they depend on the lane alone.
+// twr[r - 1] = tw[(r - 1) * NS + l] is the twiddle of the lane's FIRST butterfly (m = 0); for m > 0 the index moves by L m and
+// the twiddle by the constant factor exp(-2 pi i r L m / (NS R)) -- a 16th root of unity for the last stage of the 2048-point
+// plan (L = 128, NS = 256, R = 8), applied to the value first (rot16: two packed operations, none for r = 4).  Seven values in
+// 14 VGPRs instead of 14 KB of LDS that the x pass no longer needs.
+template <int Q>   // v * exp(-2 pi i Q / 16)
+__device__ __forceinline__ cf rot16(cf v) {
+  constexpr int q = ((Q % 16) + 16) % 16;
+  if constexpr (q == 0) return v;
+  else if constexpr (q == 4) return cmul_mi(v);
+  else if constexpr (q == 8) return make_float2(-v.x, -v.y);
+  else if constexpr (q == 12) return make_float2(-v.y, v.x);
+  else if constexpr (q == 2) return make_float2((v.x + v.y) * VPS_SQRT1_2, (v.y - v.x) * VPS_SQRT1_2);
+  else if constexpr (q == 6) return make_float2((v.y - v.x) * VPS_SQRT1_2, -(v.x + v.y) * VPS_SQRT1_2);
+  else if constexpr (q == 10) return make_float2(-(v.x + v.y) * VPS_SQRT1_2, (v.x - v.y) * VPS_SQRT1_2);
+  else if constexpr (q == 14) return make_float2((v.x - v.y) * VPS_SQRT1_2, (v.x + v.y) * VPS_SQRT1_2);
+  else {
+    // odd q: cos / sin of q pi / 8 from the pi / 8 pair
+    constexpr float c = (q == 1 || q == 15) ? VPS_COS_PI_8 : (q == 3 || q == 13) ? VPS_SIN_PI_8 : (q == 5 || q == 11) ? -VPS_SIN_PI_8 : -VPS_COS_PI_8;
+    constexpr float sn = (q == 1 || q == 7) ? VPS_SIN_PI_8 : (q == 3 || q == 5) ? VPS_COS_PI_8 : (q == 9 || q == 15) ? -VPS_SIN_PI_8 : -VPS_COS_PI_8;
+    return cmul(v, make_float2(c, -sn));   // exp(-i q pi / 8) = cos - i sin
+  }
+}
+template <int NC, int L, int RL, int R, int NS>
+struct RegTwiddles {
+  static constexpr int NB = RL / R;
+  // the step of the twiddle angle from one butterfly of a lane to the next, in 16ths of a turn per unit of r
+  static constexpr bool OK = (L * (NB - 1) < NS) && ((16 * L) % (NS * R) == 0);
+  static constexpr int STEP16 = OK ? (16 * L) / (NS * R) : 0;
+};
+template <int NC, int L, int RL, int R, int NS, int M, int RR>
+__device__ __forceinline__ void twiddle_reg_apply(cf (&v)[RL], const cf* twr) {
+  if constexpr (RR < R) {
+    v[M * R + RR] = cmul(rot16<RegTwiddles<NC, L, RL, R, NS>::STEP16 * M * RR>(v[M * R + RR]), twr[RR - 1]);
+    twiddle_reg_apply<NC, L, RL, R, NS, M, RR + 1>(v, twr);
+  }
+}
+template <int NC, int L, int RL, int R, int NS, int M = 0>
+__device__ __forceinline__ void twiddle_butterfly_reg(cf (&v)[RL], const cf* twr) {
+  static_assert(RegTwiddles<NC, L, RL, R, NS>::OK, "register twiddles: constant 16th-root steps between a lane's butterflies");
+  if constexpr (M < RL / R) {
+    twiddle_reg_apply<NC, L, RL, R, NS, M, 1>(v, twr);
+    Dft<R>::run(&v[M * R]);
+    twiddle_butterfly_reg<NC, L, RL, R, NS, M + 1>(v, twr);
+  }
+}
+template <int NC, int L, int RL, int R, int NS>
+__device__ __forceinline__ void load_stage_twiddles(cf (&twr)[R - 1], const cf* __restrict__ tw_global, int l) {
+#pragma unroll
+  for (int r = 1; r < R; ++r) twr[r - 1] = tw_global[(r - 1) * NS + l % NS];
+}
+
 template <int NC, int L, int RL, int R, int NS>
 __device__ __forceinline__ void lds_store_stage(const cf (&v)[RL], cf* line, int l) {
   constexpr int NB = RL / R;
@@ -465,8 +517,8 @@ __device__ __forceinline__ void rows_transpose4(float& x0, float& x1, float& x2,
 // Runs stages 1.. (stage 0 inputs already in v).  On return v holds the spectrum:
 // v[m*RLAST + r] = F[l + L*m + r*NC/RLAST].  L lanes per line (default: the plan's; the persistent transposing pass
 // of the longest lines runs a line on half as many lanes with twice the points each).
-template <int NC, int L, bool WAVE>
-__device__ __forceinline__ void fft_from_regs_l(cf (&v)[NC / L], cf* line, const cf* tw, int l) {
+template <int NC, int L, bool WAVE, bool TWREG = false>
+__device__ __forceinline__ void fft_from_regs_l(cf (&v)[NC / L], cf* line, const cf* tw, int l, const cf* twr = nullptr) {
   typedef PlanInfo<NC> PI;
   constexpr int RL = NC / L;
   static_assert(RL % PI::R0 == 0 && RL % PI::R1 == 0 && RL % PI::R2 == 0, "radix must divide RL");
@@ -496,13 +548,16 @@ __device__ __forceinline__ void fft_from_regs_l(cf (&v)[NC / L], cf* line, const
         exchange_sync<WAVE>();
         lds_load_stage<NC, L, RL, PI::R2>(v, line, l);
       }
-      twiddle_butterfly<NC, L, RL, PI::R2, PI::NS2>(v, tw + PI::TW1, l);
+      if constexpr (TWREG)
+        twiddle_butterfly_reg<NC, L, RL, PI::R2, PI::NS2>(v, twr);
+      else
+        twiddle_butterfly<NC, L, RL, PI::R2, PI::NS2>(v, tw + PI::TW1, l);
     }
   }
 }
-template <int NC, bool WAVE = false>
-__device__ __forceinline__ void fft_from_regs(cf (&v)[PlanInfo<NC>::RL], cf* line, const cf* tw, int l) {
-  fft_from_regs_l<NC, PlanInfo<NC>::L, WAVE>(v, line, tw, l);
+template <int NC, bool WAVE = false, bool TWREG = false>
+__device__ __forceinline__ void fft_from_regs(cf (&v)[PlanInfo<NC>::RL], cf* line, const cf* tw, int l, const cf* twr = nullptr) {
+  fft_from_regs_l<NC, PlanInfo<NC>::L, WAVE, TWREG>(v, line, tw, l, twr);
 }
 
 template <int NC>
@@ -954,11 +1009,18 @@ constexpr int pencil_lanes() {
   return (NC >= 1024 && VPS_PENCIL_HALF_LANES_LONG) ? PlanInfo<NC>::L / 2 : PlanInfo<NC>::L;
 }
 
+// Epilogue of 8-line pencils (2048- and 4096-cell lines; measured at C4, ms per launch, vector / energy): 8-byte streaming
+// stores 29.5 / 11.5 (rounds 2-3); 8-byte plain 30.6 / 10.95; 16-byte streaming 27.4 / 12.4; 16-byte plain 27.0 / 10.2 -- the
+// epilogue is bound by store ISSUE (half the instructions with dwordx4), and the energy launch, whose workgroups live for one
+// component only, merges its half lines in L2 better when they are not marked streaming.
 #ifndef VPS_ST16_MODE
-#define VPS_ST16_MODE 0
+#define VPS_ST16_MODE 3   // bit 0: vector launches, bit 1: the energy launch
 #endif
 #ifndef VPS_PLAIN_MODE
-#define VPS_PLAIN_MODE 0
+#define VPS_PLAIN_MODE 2
+#endif
+#ifndef VPS_ST16_ALL
+#define VPS_ST16_ALL 0    // 1: 16-byte stores for 16-line pencils too (experiment)
 #endif
 template <int NC, int TP, bool ENERGY = false>
 __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()) pencil_fft_z_kernel(const PencilParams p) {
@@ -1166,7 +1228,7 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
     // epilogue flavour of 8-line pencils (64-byte output segments): 16-byte stores and / or plain instead of streaming stores,
     // per kernel (bit 0: vector launches, bit 1: the energy launch) -- measured at C4, DESIGN.md section 7
     constexpr int WHO = ENERGY ? 2 : 1;
-    constexpr bool ST16 = (VPS_ST16_MODE & WHO) && TP == 8 && (NC & 1) == 0 && ((NC / 2) * (TP / 2)) % NT == 0;
+    constexpr bool ST16 = (VPS_ST16_MODE & WHO) && TP >= 8 && TP <= 16 && (VPS_ST16_ALL || TP == 8) && (NC & 1) == 0 && ((NC / 2) * (TP / 2)) % NT == 0;
     constexpr bool PLAIN = (VPS_PLAIN_MODE & WHO) && TP < 16;
     if constexpr (ST16)
       r2c_store_tile16<NC, TP, NT, PLAIN>(buf, tidc, p.tw_r2c, out, N, nyq);
@@ -1250,6 +1312,11 @@ struct XParams {
                       // block and holds the rows |ky| <= ptab[i].y (-1: all N), see PassParams::ptab; its kz is kz0 + i * kz_step
   int kz_step;
   int pair;  // FAST path: tiles pair ky with N-ky (needs whole ky ranges: line0, nlines multiples of N)
+  // integer shells (FAST == 2; vps_set_binning has checked that they reproduce the float64 comparison bit for bit): a mode
+  // belongs to shell b iff nthr[b] <= ix^2 + iy^2 + iz^2 < nthr[b + 1] (signed mode indices); nmax = nthr[nbins]; kf = 2 pi / L
+  const unsigned* nthr;
+  unsigned nmax;
+  float kf;
   double* part_sum;    // [grid][nbins] per-workgroup partial shell sums
   unsigned* part_cnt;  // [grid][nbins] per-workgroup partial shell counts
 };
@@ -1258,20 +1325,40 @@ struct XParams {
 // [0, N/2] -- true for 2 pi fftfreq -- so kx and -kx share one s and one shell: a lane
 // then walks RL/2 values of |kx|, adds the two mirrored |F|^2 and issues one LDS atomic
 // per |kx|, with no per-element branches (the host checks the table, vps_set_binning).
-template <int NC, int T, int MODE, bool SEG, bool COUNT, bool FAST>
+// FASTMODE 2 = FAST with INTEGER shells: in units of (2 pi / L)^2 the reference's s = (kx^2 + ky^2) + kz^2 is the integer
+// n = ix^2 + iy^2 + iz^2 up to float64 rounding, and where no shell threshold lies within 1e-9 (relative) of an integer --
+// both reference flavours: their edges are half-integer multiples of 2 pi / L -- the float64 comparison thr[b] <= s < thr[b+1]
+// and the integer comparison nthr[b] <= n < nthr[b+1] (nthr[b] = ceil(thr[b] / k2[1])) decide every mode alike.  The kernel
+// then needs no k^2 table at all: no float64 registers or adds per mode, 4-byte thresholds, and nothing to load per tile or
+// per line (tile_beyond_shells / locate_line are arithmetic on the tile index).  vps_set_binning checks the condition and
+// falls back to FASTMODE 1 where it fails (custom k ranges with edges on integer multiples).
+// With integer shells the 2048-point plan also keeps its last stage's twiddles in registers (x_twreg): thresholds 4 KB + sums
+// 8 KB + counts 4 KB + stage-1 twiddles 2 KB + two lines 34 KB = 52 KB, so THREE workgroups share a CU instead of two
+// (70.6 KB before).  Measured at C4: persistent workgroups per CU 1 -> 2: 35.7 -> 22.7 ms per vector launch.
+// (Lines made of segments -- the received blocks of a slab exchange -- keep the twiddles in LDS: with the segment arithmetic
+//  next to 14 twiddle registers the kernel does not fit the 168 VGPRs of three waves per SIMD: 97 registers spilled.)
+template <int NC, int FASTMODE, bool SEG>
+constexpr bool x_twreg() {
+  return FASTMODE == 2 && !SEG && NC == 2048 && PlanInfo<NC>::R2 > 1;
+}
+template <int NC, int T, int MODE, bool SEG, bool COUNT, int FASTMODE>
 #ifndef VPS_X_MIN_WAVES
 #define VPS_X_MIN_WAVES 1
 #endif
-__global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pass(const XParams p) {
+__global__ void __launch_bounds__(T* PlanInfo<NC>::L, (x_twreg<NC, FASTMODE, SEG>() ? 3 : VPS_X_MIN_WAVES)) fft_x_pass(const XParams p) {
   typedef PlanInfo<NC> PI;
+  constexpr bool FAST = FASTMODE != 0, INTB = FASTMODE == 2, TWREG = x_twreg<NC, FASTMODE, SEG>();
   constexpr int L = PI::L, RL = PI::RL, NT = T * L;
   constexpr int H = RL / 2;   // |kx| values per lane on the FAST path
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  // carve: thr (double, nbins+2 with a +inf sentinel) | hsum (double) | tw | line buffers | hcnt
+  // carve: thr (double, nbins+2 with a +inf sentinel; INTB: unsigned, 0xffffffff sentinel) | hsum (double) | tw | line buffers | hcnt
   double* thr = reinterpret_cast<double*>(smem_raw);
-  double* hsum = thr + (MODE == 0 ? (p.nbins + 2) : 0);
+  unsigned* nthr = reinterpret_cast<unsigned*>(smem_raw);
+  double* hsum = INTB ? reinterpret_cast<double*>(nthr + ((p.nbins + 3) & ~1)) : thr + (MODE == 0 ? (p.nbins + 2) : 0);
   cf* tw_lds = reinterpret_cast<cf*>(hsum + (MODE == 0 ? p.nbins : 0));
-  cf* buf = tw_lds + PI::TWL;
+  constexpr int TWCOPY = TWREG ? PI::TW1 : PI::TW;                      // twiddle entries staged in LDS
+  constexpr int TWRES = TWREG ? ((PI::TW1 + 1) & ~1) : PI::TWL;         // ... and reserved for them
+  cf* buf = tw_lds + TWRES;
   const cf* tw = PI::TWLDS ? tw_lds : p.tw_stage;
   unsigned* hcnt = reinterpret_cast<unsigned*>(buf + T * PI::PITCH);
   float* wl = reinterpret_cast<float*>(hcnt + ((MODE == 0 && COUNT) ? p.nbins : 0));   // [NC] window factors (MODE 0 with p.win)
@@ -1279,20 +1366,27 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pas
   const int tid = threadIdx.x;
   const int t = tid / L, l = tid % L;
   if constexpr (PI::TWLDS)
-    for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
+    for (int i = tid; i < TWCOPY; i += NT) tw_lds[i] = p.tw_stage[i];
+  cf twr[TWREG ? (PI::R2 - 1) : 1];
+  if constexpr (TWREG) load_stage_twiddles<NC, L, RL, PI::R2, PI::NS2>(twr, p.tw_stage + PI::TW1, l);
   // fl(kx*kx) of this lane's contiguous chunk of RL kx values, ordered by non-decreasing
   // |kx|: the chunks of the negative-frequency half (index >= NC/2) are walked backwards
-  double k2x[MODE == 0 ? (FAST ? H : RL) : 1];
+  double k2x[(MODE == 0 && !INTB) ? (FAST ? H : RL) : 1];
   const bool rev = (l * RL) >= NC / 2;
   if constexpr (MODE == 0) {
-    for (int i = tid; i <= p.nbins + 1; i += NT) thr[i] = (i <= p.nbins) ? p.thr[i] : INFINITY;
+    if constexpr (INTB) {
+      for (int i = tid; i <= p.nbins + 1; i += NT) nthr[i] = (i <= p.nbins) ? p.nthr[i] : 0xffffffffu;
+    } else {
+      for (int i = tid; i <= p.nbins + 1; i += NT) thr[i] = (i <= p.nbins) ? p.thr[i] : INFINITY;
+    }
     for (int i = tid; i < p.nbins; i += NT) {
       hsum[i] = 0.0;
       if constexpr (COUNT) hcnt[i] = 0u;
     }
     if (p.win)
       for (int i = tid; i < NC; i += NT) wl[i] = p.win[i];
-    if constexpr (FAST) {
+    if constexpr (INTB) {
+    } else if constexpr (FAST) {
 #pragma unroll
       for (int i = 0; i < H; ++i) k2x[i] = p.k2[l * H + i];
     } else {
@@ -1323,10 +1417,11 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pas
   long long li = 0, lrow = 0;   // line index inside the launch's range, and the row of the input it is read from
   bool live = false, mirrored = false, has_partner = false;
   double k2y = 0.0, k2z = 0.0;   // fl(ky*ky), fl(kz*kz) of the line (MODE 0)
+  unsigned nyz = 0u;             // INTB: iy^2 + iz^2 of the line
   float wyz = 1.f;               // window factor of the line's (ky, kz)
   unsigned wz = 1u;              // Hermitian multiplicity of its kz plane
   double k2half = 0.0;
-  if constexpr (MODE == 0) k2half = p.k2[NC / 2];
+  if constexpr (MODE == 0 && !INTB) k2half = p.k2[NC / 2];
   cf v[RL];
   // PAIR tiles whose smallest |ky| already puts every mode of the tile beyond the last shell edge -- fl(ky^2 + kz^2) >=
   // thr[nbins], and s = (kx^2 + ky^2) + kz^2 can only be larger -- are neither loaded nor transformed: with the default
@@ -1342,7 +1437,12 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pas
     if constexpr (MODE == 0 && FAST) {
       if (pair) {
         const int kz = p.kz0 + ((int)(p.line0 / NC) + (int)(tile / tiles_per_plane)) * p.kz_step;
-        return (p.k2[tile_q(tile) * TH] + p.k2[kz]) >= p.thr[p.nbins];
+        if constexpr (INTB) {
+          const unsigned ka = (unsigned)(tile_q(tile) * TH);
+          return ka * ka + (unsigned)kz * (unsigned)kz >= p.nmax;
+        } else {
+          return (p.k2[tile_q(tile) * TH] + p.k2[kz]) >= p.thr[p.nbins];
+        }
       }
     }
     return false;
@@ -1373,8 +1473,14 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pas
         const long long g = p.line0 + li;
         // (lines of the x pass have N = NC points: a compile-time divisor instead of a 64-bit division per tile and thread)
         const int kz = p.kz0 + (int)(g / NC) * p.kz_step;
-        k2y = p.k2[(int)(g % NC)];
-        k2z = p.k2[kz];
+        if constexpr (INTB) {
+          const int kyi = (int)(g % NC);
+          const unsigned iy = (unsigned)(2 * kyi <= NC ? kyi : NC - kyi);
+          nyz = iy * iy + (unsigned)kz * (unsigned)kz;
+        } else {
+          k2y = p.k2[(int)(g % NC)];
+          k2z = p.k2[kz];
+        }
         wz = (kz == 0 || 2 * kz == NC) ? 1u : 2u;
         if (p.win) wyz = p.win[(int)(g % NC)] * p.win[kz];
       }
@@ -1392,13 +1498,22 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pas
         const unsigned long long ub = reinterpret_cast<unsigned long long>(base);
         const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)ub), bhi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
         const cf* sbase = reinterpret_cast<const cf*>(((unsigned long long)bhi << 32) | blo);
+        // (the shift through an empty asm: the RL segment offsets are loop-invariant, and hoisted out of the tile loop they
+        //  sit in ~2 RL VGPRs for the whole kernel -- the scalar file is full -- which spills the register-twiddle variant;
+        //  formed where they are used they are a handful of scalar operations per load)
+        int sh = p.seg_shift;
+        asm volatile("" : "+s"(sh));
+        const int smask = (1 << sh) - 1;
 #pragma unroll
         for (int m = 0; m < NB; ++m)
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const int xr = L * m + r * (NC / R);
-            const long long off = (long long)(xr >> p.seg_shift) * p.seg_stride + (xr & segmask);
-            const double raw = live ? __builtin_nontemporal_load(reinterpret_cast<const double*>(&sbase[off + l])) : 0.0;
+            const long long off = (long long)(xr >> sh) * p.seg_stride + (xr & smask);
+            // (uniform 64-bit base + zero-extended 32-bit lane offset: the saddr + voffset form of global_load, one VGPR of
+            //  address for all loads instead of a 64-bit VGPR pair each)
+            const char* sb = reinterpret_cast<const char*>(sbase + off);
+            const double raw = live ? __builtin_nontemporal_load(reinterpret_cast<const double*>(sb + (unsigned)l * 8u)) : 0.0;
             v[m * R + r] = *reinterpret_cast<const cf*>(&raw);
           }
         return;
@@ -1414,8 +1529,10 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pas
           // (this exact form -- a conditional double load, reinterpreted -- keeps every load a streaming one
           // with one base register and immediate offsets; going through load_stream() did not)
           // (seg_shift < 0: segment length not a power of two -- the 2^a 5^b grids on several ranks)
-          const int sg = p.seg_shift >= 0 ? (x >> p.seg_shift) : x / p.seglen;
-          const int so = p.seg_shift >= 0 ? (x & segmask) : x - sg * p.seglen;
+          // (a power-of-two line divides into power-of-two segments only: no division path to compile, or to keep registers for)
+          constexpr bool POW2 = (NC & (NC - 1)) == 0;
+          const int sg = (POW2 || p.seg_shift >= 0) ? (x >> p.seg_shift) : x / p.seglen;
+          const int so = (POW2 || p.seg_shift >= 0) ? (x & segmask) : x - sg * p.seglen;
           const double raw = live ? __builtin_nontemporal_load(reinterpret_cast<const double*>(
                                         &base[(long long)sg * p.seg_stride + so]))
                                   : 0.0;
@@ -1443,11 +1560,12 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pas
     const long long li_cur = li;
     const bool live_cur = live, mirrored_cur = mirrored, partner_cur = has_partner;
     const double k2y_cur = k2y, k2z_cur = k2z;
+    const unsigned nyz_cur = nyz;
     const unsigned wz_cur = wz;
     const float wyz_cur = wyz;
     if constexpr (MODE != 0) {
       exchange_sync<WSYNC>();  // previous tile's readers are done with the line buffers
-      fft_from_regs<NC, WSYNC>(v, line, tw, l);
+      fft_from_regs<NC, WSYNC, TWREG>(v, line, tw, l, twr);
     }
     if constexpr (MODE == 1) {
       if (live_cur) {
@@ -1494,7 +1612,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pas
         }
 #endif
         exchange_sync<WSYNC>();  // previous readers are done with the line buffers
-        fft_from_regs<NC, WSYNC>(v, line, tw, lc);
+        fft_from_regs<NC, WSYNC, TWREG>(v, line, tw, lc, twr);
 #pragma unroll
         for (int i = 0; i < RL; ++i) {
           const float a = v[i].x * v[i].x + v[i].y * v[i].y;
@@ -1541,12 +1659,23 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pas
           // are uniform (checked by vps_set_binning), so the float guess is off by at most
           // one shell and is corrected against the exact float64 thresholds.
           auto bin_one = [&](int i, double k2xi) {
+            int bin;
+            if constexpr (INTB) {
+              // n = ix^2 + iy^2 + iz^2: the float guess is within one shell, the integer thresholds decide
+              const unsigned ix = (unsigned)(l * H + i);
+              const unsigned n = ix * ix + nyz_cur;
+              int g = (int)((sqrtf((float)n) * p.kf - p.edge0) * p.inv_spacing);
+              g = min(max(g, 0), p.nbins - 1);
+              const unsigned lo = nthr[g], hi = nthr[g + 1];
+              bin = g - ((n < lo) ? 1 : 0) + ((n >= hi) ? 1 : 0);
+            } else {
             // s = (kx*kx + ky*ky) + kz*kz with numpy's rounding (the table holds fl(k*k))
             const double s = (k2xi + k2y_cur) + k2z_cur;
             int g = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
             g = min(max(g, 0), p.nbins - 1);
             const double lo = thr[g], hi = thr[g + 1];
-            const int bin = g - ((s < lo) ? 1 : 0) + ((s >= hi) ? 1 : 0);
+            bin = g - ((s < lo) ? 1 : 0) + ((s >= hi) ? 1 : 0);
+            }
             float pv = mine[i];
             if (partner_cur) pv += mine[i + POFF];
             unsigned c = 1u;
@@ -1571,13 +1700,21 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, VPS_X_MIN_WAVES) fft_x_pas
           };
 #ifndef VPS_ABL_X_NOBIN
 #pragma unroll
-          for (int i = 0; i < H; ++i) bin_one(i, k2x[i]);
+          for (int i = 0; i < H; ++i) bin_one(i, INTB ? 0.0 : k2x[INTB ? 0 : i]);
 #endif
           if (l == L - 1) {   // the unpaired kx = NC/2 mode
+            int bin;
+            if constexpr (INTB) {
+              const unsigned n = (unsigned)(NC / 2) * (unsigned)(NC / 2) + nyz_cur;
+              int g = (int)((sqrtf((float)n) * p.kf - p.edge0) * p.inv_spacing);
+              g = min(max(g, 0), p.nbins - 1);
+              bin = g - ((n < nthr[g]) ? 1 : 0) + ((n >= nthr[g + 1]) ? 1 : 0);
+            } else {
             const double s = (k2half + k2y_cur) + k2z_cur;
             int g = (int)((sqrtf((float)s) - p.edge0) * p.inv_spacing);
             g = min(max(g, 0), p.nbins - 1);
-            const int bin = g - ((s < thr[g]) ? 1 : 0) + ((s >= thr[g + 1]) ? 1 : 0);
+            bin = g - ((s < thr[g]) ? 1 : 0) + ((s >= thr[g + 1]) ? 1 : 0);
+            }
             if ((unsigned)bin < (unsigned)p.nbins) {
               float pv = pw[NC / 2 + L];
               if (partner_cur) pv += pw[NC / 2 + L + POFF];
@@ -1785,18 +1922,22 @@ int launch_transpose(vps_ctx* ctx, const PassParams& p, int kind) {
 }
 
 template <int NC, int MODE, bool COUNT = false>
-int launch_x(vps_ctx* ctx, const XParams& p_in, bool fast = false) {
+int launch_x(vps_ctx* ctx, const XParams& p_in, int fast = 0) {   // fast: 0 general shell walk, 1 mirrored kx (float64), 2 integer shells
   XParams p = p_in;
   constexpr int T = xpass_T<NC>();
   typedef PlanInfo<NC> PI;
-  size_t lds = (PI::TWL + (size_t)T * PI::PITCH) * sizeof(cf);
-  if (MODE == 0) lds += (size_t)(2 * p.nbins + 2) * sizeof(double) + (COUNT ? (size_t)p.nbins * sizeof(unsigned) : 0) +
+  if (!(MODE == 0 && NC >= 32)) fast = 0;
+  const bool seg = p.seglen != NC;
+  const bool twreg = fast == 2 && !seg && x_twreg<NC, 2, false>();
+  size_t lds = ((twreg ? ((PI::TW1 + 1) & ~1) : PI::TWL) + (size_t)T * PI::PITCH) * sizeof(cf);
+  if (MODE == 0) lds += (fast == 2 ? (size_t)((p.nbins + 3) & ~1) * sizeof(unsigned) : (size_t)(p.nbins + 2) * sizeof(double)) +
+                        (size_t)p.nbins * sizeof(double) + (COUNT ? (size_t)p.nbins * sizeof(unsigned) : 0) +
                         (p.win ? (size_t)NC * sizeof(float) : 0);
   if (lds > ctx->lds_per_cu) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "x pass needs %zu B LDS", lds);
-  const bool seg = p.seglen != NC;
-  auto kern = seg ? fft_x_pass<NC, T, MODE, true, COUNT, false> : fft_x_pass<NC, T, MODE, false, COUNT, false>;
+  auto kern = seg ? fft_x_pass<NC, T, MODE, true, COUNT, 0> : fft_x_pass<NC, T, MODE, false, COUNT, 0>;
   if constexpr (MODE == 0 && NC >= 32) {
-    if (fast) kern = seg ? fft_x_pass<NC, T, MODE, true, COUNT, true> : fft_x_pass<NC, T, MODE, false, COUNT, true>;
+    if (fast == 1) kern = seg ? fft_x_pass<NC, T, MODE, true, COUNT, 1> : fft_x_pass<NC, T, MODE, false, COUNT, 1>;
+    if (fast == 2) kern = seg ? fft_x_pass<NC, T, MODE, true, COUNT, 2> : fft_x_pass<NC, T, MODE, false, COUNT, 2>;
   }
   if (lds > 64 * 1024)
     VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1953,9 +2094,9 @@ int VPS_PARTFN(vps_fftpart_x)(vps_ctx* ctx, int NC, int mode, int count, const v
   const XParams& p = *static_cast<const XParams*>(params);
   int rc = VPS_OK;
   if (mode == 0 && count) {
-    VPS_DISPATCH_NC(NC, (rc = launch_x<NC_, 0, true>(ctx, p, fast != 0)));
+    VPS_DISPATCH_NC(NC, (rc = launch_x<NC_, 0, true>(ctx, p, fast)));
   } else if (mode == 0) {
-    VPS_DISPATCH_NC(NC, (rc = launch_x<NC_, 0, false>(ctx, p, fast != 0)));
+    VPS_DISPATCH_NC(NC, (rc = launch_x<NC_, 0, false>(ctx, p, fast)));
   } else if (mode == 1) {
     VPS_DISPATCH_NC(NC, (rc = launch_x<NC_, 1>(ctx, p)));
   } else if (mode == 2) {
@@ -2415,10 +2556,14 @@ static int fft_x_impl(vps_ctx* ctx, int N, int64_t nlines, int64_t line0, int kz
     p.psum = psum_dev;
     p.nsample = nsample_dev;
     p.pair = (ctx->bin_fast && line0 % N == 0 && nlines % N == 0 && vps_option("no_pair_binning", 0) == 0) ? 1 : 0;
+    p.nthr = ctx->d_nthr;
+    p.nmax = ctx->bin_nmax;
+    p.kf = ctx->bin_kf;
+    const int fastmode = !ctx->bin_fast ? 0 : (ctx->bin_int && ctx->d_nthr && vps_option("no_int_binning", 0) == 0) ? 2 : 1;
     if (mode == 0) {
-      rc = route_x(ctx, N, 0, 1, p, ctx->bin_fast ? 1 : 0);
+      rc = route_x(ctx, N, 0, 1, p, fastmode);
     } else {
-      rc = route_x(ctx, N, 0, 0, p, ctx->bin_fast ? 1 : 0);
+      rc = route_x(ctx, N, 0, 0, p, fastmode);
     }
   } else if (mode == 1) {
     if (!out_dev) return vps_fail(ctx, VPS_ERR_ARG, "null output");

@@ -38,6 +38,12 @@ struct vps_ctx {
   double* d_thr = nullptr;  // [nbins+1]
   double edge0 = 0.0, inv_spacing = 0.0;
   bool bin_fast = false;    // k2 table symmetric and monotone: mirrored-kx binning is valid
+  // integer shells (fft.hip: FASTMODE 2): k2[i] = i^2 k2[1] to rounding and no threshold within 1e-9 of an integer multiple of
+  // k2[1] -- then nthr[b] = ceil(thr[b] / k2[1]) decides every mode exactly like the float64 comparison
+  bool bin_int = false;
+  unsigned* d_nthr = nullptr;   // [nbins + 1]
+  unsigned bin_nmax = 0;        // nthr[nbins]
+  float bin_kf = 0.f;           // sqrt(k2[1])
   std::vector<double> h_k2, h_thr;  // host copies, to skip re-uploading identical tables
 
   // y-pass store cut for binning-only consumers (vps_set_bin_only): kcut[kz] = largest |ky| index whose modes can still reach
@@ -108,7 +114,8 @@ struct vps_device_guard {
 struct vps_launch_timer {
   vps_ctx* ctx;
   int idx = -1;
-  vps_launch_timer(vps_ctx* c, int kind);
+  hipStream_t stream;
+  vps_launch_timer(vps_ctx* c, int kind, hipStream_t on = nullptr);   // on: the stream the interval lives on (default: the context's)
   ~vps_launch_timer();
 };
 

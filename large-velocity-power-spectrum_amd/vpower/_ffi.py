@@ -32,6 +32,7 @@ SYMBOLS = (
     ("vps_set_option", C.c_int, (C.c_char_p, C.c_double)),
     ("vps_get_option", C.c_double, (C.c_char_p, C.c_double)),
     ("vps_device_info", C.c_int, (_vp, C.POINTER(_i64))),
+    ("vps_binning_mode", C.c_int, (_vp,)),
     ("vps_malloc", C.c_int, (_vp, C.POINTER(_vp), C.c_size_t)),
     ("vps_free", C.c_int, (_vp, _vp)),
     ("vps_memset", C.c_int, (_vp, _vp, C.c_int, C.c_size_t)),
@@ -104,11 +105,13 @@ SYMBOLS = (
     ("vps_hist_pairs", C.c_int, (_vp, _vp, _vp, _i64, _dp, C.c_int, _vp, _vp)),
 )
 
-K_DEPOSIT, K_ALGEBRA, K_FFT_Z, K_FFT_Y, K_FFT_X, K_NN_BUILD, K_NN_QUERY, K_MISC = range(8)
+K_DEPOSIT, K_ALGEBRA, K_FFT_Z, K_FFT_Y, K_FFT_X, K_NN_BUILD, K_NN_QUERY, K_MISC, K_EXCHANGE, K_EXCHANGE_WAIT = range(10)
 KERNEL_KINDS = {"deposit": K_DEPOSIT, "algebra": K_ALGEBRA, "fft_z": K_FFT_Z, "fft_y": K_FFT_Y,
-                "fft_x": K_FFT_X, "nn_build": K_NN_BUILD, "nn_query": K_NN_QUERY, "misc": K_MISC}
+                "fft_x": K_FFT_X, "nn_build": K_NN_BUILD, "nn_query": K_NN_QUERY, "misc": K_MISC,
+                "exchange": K_EXCHANGE, "exchange_wait": K_EXCHANGE_WAIT}
 
 
+ABI_VERSION = 5   # include/vps_hip.h: VPS_ABI_VERSION
 FFT_PARTS = 4   # fft.hip is compiled once per family of line lengths (-DVPS_FFT_PART=k)
 
 
@@ -201,7 +204,7 @@ def lib():
 # variables VPS_OPT_<NAME> (e.g. VPS_OPT_NN_KAPPA=1.3) are mapped ONCE, here, and recorded in OPTIONS so that a run can
 # report them.
 OPTION_NAMES = ("no_fast_binning", "no_pair_binning", "nn_query_centric", "nn_column", "nn_build_atomic", "nn_kappa", "nn_stats", "sort_groups",
-                "sort_staged", "sort_atomic", "nn_ablate")
+                "sort_staged", "sort_atomic", "nn_ablate", "no_int_binning", "x_wg_per_cu")
 OPTIONS = {}
 
 

@@ -426,6 +426,11 @@ class HipKernels:
         self._chk(self.lib.vps_set_binning(self.ctx, N, _ffi.as_dp(k2), _ffi.as_dp(thr), len(thr) - 1,
                                            float(edge0), float(inv_spacing)))
 
+    def binning_mode(self):
+        """How the binning x pass decides shells for the tables set last (vps_binning_mode): 0 general shell walk, 1 mirrored kx
+        with float64 k^2 sums, 2 mirrored kx with integer ix^2 + iy^2 + iz^2 (the same shells, checked by vps_set_binning)."""
+        return int(self.lib.vps_binning_mode(self.ctx))
+
     def binning_only(self):
         """Context manager: inside it the y passes skip rows whose modes all lie beyond the last shell edge of the
         binning tables set last (vps_set_bin_only) -- for outputs that go straight into the binning x pass."""
@@ -903,73 +908,115 @@ class PowerPipeline:
         import contextlib
         return self.k.binning_only() if hasattr(self.k, "binning_only") else contextlib.nullcontext()
 
-    def start_zimages(self, zimgs):
-        """First half of `accumulate_zimages`: per group of up to three components and per kz chunk, the y pass into
-        the send buffer and the all-to-all, all started asynchronously.  Returns what `finish_zimages` needs (the
-        handles AND the row packing the send buffers were written with).  Between the two calls the caller may enqueue
-        other work (the next quantity's deposit + z pass): it overlaps the exchanges."""
+    # -- the chunk pipeline of the slab exchange ------------------------------------------------------------------------
+    # A JOB is one kz chunk of up to three z images (the components of a vector quantity share one binning launch): y pass
+    # into fresh send buffers -> all-to-all (asynchronous) -> x pass + shell sums of the received blocks.  Jobs are started
+    # in order and at most `inflight_max` of them (VPS_A2A_INFLIGHT, default 2) are between their start and their x pass:
+    # job j + 1 crosses the node while job j is binned, and only TWO chunks' send / receive buffers are alive, whatever the
+    # chunk count -- not the whole field twice over.  The jobs of several quantities form ONE sequence: the next quantity's
+    # deposit + z pass is enqueued while the last chunks of the previous one are still travelling.
+    def inflight_max(self):
+        try:
+            return max(1, int(os.environ.get("VPS_A2A_INFLIGHT", "2")))
+        except ValueError:
+            return 2
+
+    def _stamp(self):
+        """Timing event on the current stream (instrumented steps only: `self.instr` is a list)."""
+        if getattr(self, "instr", None) is None or not torch.cuda.is_available():
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def _start_chunk(self, comps, c, packed):
         N, nx, G = self.N, self.nx, self.comm.world
-        k = self.k
-        C_ = self.nchunks
+        sends = [self.k.fft_y_chunk(z, N, nx, G, self.nchunks, c) for z in comps]
+        t0 = self._stamp()
+        return {"handles": [self.comm.all_to_all_start(s_) for s_ in sends], "chunk": c, "packed": packed, "t0": t0}
+
+    def _finish_chunk(self, job, psum, nsample, count):
+        N, nx, G, r = self.N, self.nx, self.comm.world, self.comm.rank
+        t1 = self._stamp()
+        recvs = [self.comm.all_to_all_finish(h) for h in job["handles"]]
+        t2 = self._stamp()
+        if t1 is not None:
+            self.instr.append((job["t0"], t1, t2))      # exchange started | x pass ready to go | blocks there
+        job["handles"] = None
+        self.k.fft_x_bin_chunk(recvs, N, nx, G, self.nchunks, job["chunk"], r, job["packed"], psum, nsample, count=count)
+
+    def exchange_times(self):
+        """(exposed_ms, span_ms) of the instrumented jobs so far: the time the compute stream stood still waiting for blocks,
+        and -- meaningful when the jobs ran one at a time (inflight_max = 1) -- the time from a job's exchange start to its
+        arrival.  Synchronises."""
+        torch.cuda.synchronize()
+        ex = sum(a.elapsed_time(b) for _, a, b in self.instr)
+        span = sum(a.elapsed_time(b) for a, _, b in self.instr)
+        return ex, span
+
+    def pipelined_quantities(self, producers, accumulators, counts=None):
+        """The jobs of several quantities of ONE particle set as one bounded pipeline: producers[i]() enqueues quantity i's
+        deposit + z pass and returns its z images (one per component, which may live in the SAME buffer for every quantity:
+        by then all y passes of quantity i - 1 have been enqueued); its chunks are binned into accumulators[i] =
+        (psum, nsample).  counts[i] (default True): whether quantity i's shell counts are accumulated (first group only).
+        What `bench.py` runs on several ranks (torch transport); one quantity: `accumulate_zimages`."""
+        import collections
         group = 1 if os.environ.get("VPS_X_PER_COMPONENT") == "1" else 3
-        groups = []
+        k, C_, maxin = self.k, self.nchunks, self.inflight_max()
+        inflight = collections.deque()
+
+        def finish_oldest():
+            job, qi, cnt = inflight.popleft()
+            self._finish_chunk(job, accumulators[qi][0], accumulators[qi][1], cnt)
         self.prepare()
-        with self._bin_scope():
-            packed = k.y_packed(N) if hasattr(k, "y_packed") else False   # the blocks carry only the rows a shell can reach
+        for qi, produce in enumerate(producers):
+            zimgs = produce()
+            cnt = True if counts is None else bool(counts[qi])
             for i in range(0, len(zimgs), group):
-                comps = zimgs[i:i + group]
-                groups.append([[self.comm.all_to_all_start(k.fft_y_chunk(z, N, nx, G, C_, c)) for z in comps]
-                               for c in range(C_)])
+                for c in range(C_):
+                    while len(inflight) >= maxin:
+                        finish_oldest()
+                    with self._bin_scope():   # the blocks carry only the rows a shell can reach
+                        packed = k.y_packed(self.N) if hasattr(k, "y_packed") else False
+                        inflight.append((self._start_chunk(zimgs[i:i + group], c, packed), qi, cnt and i == 0))
+        while inflight:
+            finish_oldest()
+        return accumulators
+
+    def start_zimages(self, zimgs):
+        """Every chunk of every group of `zimgs` started at once (y pass + all-to-all); `finish_zimages` bins them.  All
+        send / receive buffers are alive in between: the bounded form is `accumulate_zimages` / `pipelined_quantities`."""
+        group = 1 if os.environ.get("VPS_X_PER_COMPONENT") == "1" else 3
+        self.prepare()
+        groups = []
+        with self._bin_scope():
+            packed = self.k.y_packed(self.N) if hasattr(self.k, "y_packed") else False
+            for i in range(0, len(zimgs), group):
+                groups.append([self._start_chunk(zimgs[i:i + group], c, packed) for c in range(self.nchunks)])
         return {"packed": packed, "groups": groups}
 
     def finish_zimages(self, started, psum=None, nsample=None, count=True):
-        """Second half: as the chunks arrive, x pass + shell sums (up to three components share one binning launch per
-        chunk: their |F|^2 are summed before the shell search)."""
-        N, nx, G, r = self.N, self.nx, self.comm.world, self.comm.rank
-        k = self.k
-        k.set_binning(*self._binning)
-        self._set_window()
+        self.prepare()
         if psum is None:
             psum, nsample = self.new_accumulators()
-        C_ = self.nchunks
-        for i, pending in enumerate(started["groups"]):
-            cnt = count and i == 0
-            for c in range(C_):
-                recvs = [self.comm.all_to_all_finish(h) for h in pending[c]]
-                pending[c] = None
-                k.fft_x_bin_chunk(recvs, N, nx, G, C_, c, r, started["packed"], psum, nsample, count=cnt)
+        for i, jobs in enumerate(started["groups"]):
+            for c in range(self.nchunks):
+                self._finish_chunk(jobs[c], psum, nsample, count and i == 0)
+                jobs[c] = None
         return psum, nsample
-
-    def pipelined_quantities(self, producers, accumulators):
-        """Several quantities of ONE particle set, pipelined against each other's exchanges: producers[i]() enqueues
-        quantity i's deposit + z pass and returns its z images (one per component); its y passes and all-to-alls are
-        started at once, and only then are the PREVIOUS quantity's arrived chunks transformed and binned into
-        accumulators[i-1] = (psum, nsample) -- so the links carry quantity i while the device works on i-1 and i+1.
-        Two quantities' send / receive buffers are alive at a time.  (What `bench.py` runs for C4 on >= 4 ranks.)"""
-        prev = None
-        for i, produce in enumerate(producers):
-            started = self.start_zimages(produce())
-            if prev is not None:
-                self.finish_zimages(prev[1], *accumulators[prev[0]])
-            prev = (i, started)
-        if prev is not None:
-            self.finish_zimages(prev[1], *accumulators[prev[0]])
-        return accumulators
 
     def accumulate_zimages(self, zimgs, psum=None, nsample=None, count=True):
         """x-side of the transform for z images (HipKernels.fft_z / deposit_fft_z): per kz chunk, y pass into the
-        send buffer, all-to-all started at once, then -- as chunks arrive -- x pass + shell sums."""
+        send buffer, all-to-all, x pass + shell sums, two chunks in flight (`pipelined_quantities`)."""
         group = 1 if os.environ.get("VPS_X_PER_COMPONENT") == "1" else 3
-        if isinstance(self.comm, LibraryComm):     # the whole chunk pipeline runs inside the library (RCCL)
+        if psum is None:
+            psum, nsample = self.new_accumulators()
+        if isinstance(self.comm, LibraryComm):     # the whole chunk pipeline runs inside the library (RCCL, two chunk slots)
             self.prepare()
-            if psum is None:
-                psum, nsample = self.new_accumulators()
             for i in range(0, len(zimgs), group):
                 self.k.spectrum_zimages(zimgs[i:i + group], self.N, self.nx, self.nchunks, psum, nsample, count=count and i == 0)
             return psum, nsample
-        for i in range(0, len(zimgs), group):      # one group in flight at a time (send + receive buffers of 3 fields)
-            psum, nsample = self.finish_zimages(self.start_zimages(zimgs[i:i + group]), psum, nsample,
-                                                count=count and i == 0)
+        self.pipelined_quantities([lambda: zimgs], [(psum, nsample)], counts=[count])
         return psum, nsample
 
     # -- stage B + C on one or more real fields of this rank's slab ---------------

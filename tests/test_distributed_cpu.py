@@ -103,15 +103,35 @@ def _pipelined_worker(rank, world, port, N, L, seed, out_dir, chunks, per_compon
                 return [K.fft_z(torch.from_numpy(np.ascontiguousarray(f[pipe.x0: pipe.x0 + pipe.nx])), N, pipe.nx) for f in fields]
             return produce
         accs = [pipe.new_accumulators() for _ in quantities]
-        # spy on the x passes: quantity i's chunks must be binned only after quantity i+1's exchanges were started
-        real_finish = pipe.finish_zimages
+        # spy on the jobs (one per kz chunk and group of components): started in order, binned in the same order, never more
+        # than `inflight_max` between start and x pass, and quantity q + 1's z images produced while q's last jobs travel
+        real_start, real_finish = pipe._start_chunk, pipe._finish_chunk
 
-        def spy_finish(started, *a, **kw):
-            order.append(("x", len([o for o in order if o[0] == "x"])))
-            return real_finish(started, *a, **kw)
-        pipe.finish_zimages = spy_finish
+        def spy_start(comps, c, packed):
+            job = real_start(comps, c, packed)
+            job["id"] = len([o for o in order if o[0] == "s"])
+            order.append(("s", job["id"]))
+            return job
+
+        def spy_finish(job, *a, **kw):
+            order.append(("x", job["id"]))
+            return real_finish(job, *a, **kw)
+        pipe._start_chunk, pipe._finish_chunk = spy_start, spy_finish
         pipe.pipelined_quantities([producer(i, f) for i, f in enumerate(quantities)], accs)
-        assert order == [("z", 0), ("z", 1), ("x", 0), ("z", 2), ("x", 1), ("x", 2)]
+        group = 1 if per_component else 3
+        njobs = [-(-len(f) // group) * chunks for f in quantities]
+        maxin = pipe.inflight_max()
+        assert maxin == 2
+        assert [o[1] for o in order if o[0] == "s"] == list(range(sum(njobs)))
+        assert [o[1] for o in order if o[0] == "x"] == list(range(sum(njobs)))
+        live = 0
+        for o in order:
+            live += {"s": 1, "x": -1, "z": 0}[o[0]]
+            assert 0 <= live <= maxin
+        for q in (1, 2):        # quantity q's z pass is enqueued before the last jobs of quantity q - 1 are binned
+            last_prev = sum(njobs[:q]) - 1
+            assert order.index(("z", q)) < order.index(("x", last_prev))
+            assert order.index(("z", q)) > order.index(("s", last_prev))
         tabs = np.stack([pipe.finish(*a) for a in accs])
         np.save(os.path.join(out_dir, f"tabs_{rank}.npy"), tabs)
     finally:
@@ -127,10 +147,11 @@ def _quantity_fields(N, seed):
 
 @pytest.mark.parametrize("world,N,chunks,per_component", [(4, 32, 2, False), (4, 64, 4, False), (2, 32, 2, True), (4, 32, 1, True)])
 def test_quantity_pipelined_exchange_matches_oracle(tmp_path, world, N, chunks, per_component):
-    """PowerPipeline.pipelined_quantities -- the branch `bench.py --gpus 8` takes for C4: quantity q+1's z images, y passes
-    and all-to-alls are started BEFORE quantity q's arrived chunks are transformed and binned, two quantities' packed send /
-    receive buffers are in flight, every quantity has its own accumulators.  Three quantities (3 + 3 + 1 components) on 2 / 4
-    gloo ranks, grouped (three components per binning launch) and per component, against the oracle's tables."""
+    """PowerPipeline.pipelined_quantities -- the branch `bench.py --gpus N` takes for C4: the kz chunks of all quantities form
+    ONE sequence of jobs (y pass -> all-to-all -> x pass + shell sums) of which two are in flight at a time, so quantity
+    q+1's deposit + z pass is enqueued while q's last chunks cross the node and only two chunks' packed send / receive buffers
+    are alive; every quantity has its own accumulators.  Three quantities (3 + 3 + 1 components) on 2 / 4 gloo ranks, grouped
+    (three components per binning launch) and per component, against the oracle's tables."""
     L, seed = 1.5, 23
     mp.spawn(_pipelined_worker, args=(world, _free_port(), N, L, seed, str(tmp_path), chunks, per_component),
              nprocs=world, join=True)

@@ -142,6 +142,32 @@ def _library_rccl_worker(rank, port, N, Np, out_dir):
         z = K.deposit_fft_z(d[0], d[1], d[2], N, 1.0, 0, N, q)
         tabs.append(pipe.finish(*pipe.accumulate_zimages([z[i] for i in range(z.shape[0])])))
         tabs.append(pipe.finish(*pipe.accumulate_zimages([z[i] for i in range(z.shape[0])])))    # buffers and events re-used
+    # workspace: two chunk slots, whatever the chunk count (it used to be every chunk of the field, send and receive)
+    ncomp = 3
+    per_chunk = [K.lib.vps_fft_y_chunk_elems(N, N, 1, 4, c) for c in range(4)]
+    assert K.lib.vps_spectrum_zimages_workspace_bytes(N, N, 1, 4, ncomp) == 2 * 2 * ncomp * max(per_chunk) * 8
+    assert K.lib.vps_spectrum_zimages_workspace_bytes(N, N, 1, 1, ncomp) == 2 * 1 * ncomp * K.lib.vps_fft_y_chunk_elems(N, N, 1, 1, 0) * 8
+    # exchange intervals on the library's communication stream, and how long the context's stream waited for them
+    z = K.deposit_fft_z(d[0], d[1], d[2], N, 1.0, 0, N, device.VELOCITY)
+    K.timing(True)
+    pipe.accumulate_zimages([z[i] for i in range(3)])
+    tim = K.timing_get()
+    K.timing(False)
+    assert tim["exchange"][0] == 4 and tim["exchange_wait"][0] == 4 and tim["exchange"][1] > 0 and tim["exchange_wait"][1] >= 0
+    # error path: the 5th ncclSend from now on (second chunk, second component) fails inside an open group -- the call
+    # reports it, the group is closed (csrc/comm_group.h), both streams are drained, and the NEXT call works and is right
+    from vpower import _ffi
+    _ffi.set_option("comm_fail_send", 5)
+    try:
+        failed = False
+        try:
+            pipe.accumulate_zimages([z[i] for i in range(3)])
+        except Exception as e:
+            failed = "ncclSend" in str(e) and "group closed" in str(e)
+        assert failed, "the injected send failure must surface as an error"
+    finally:
+        _ffi.set_option("comm_fail_send", None)
+    tabs.append(pipe.finish(*pipe.accumulate_zimages([z[i] for i in range(3)])))
     np.save(os.path.join(out_dir, "tab_lib.npy"), np.stack(tabs))
     K.comm_destroy()
 
@@ -150,7 +176,9 @@ def test_library_rccl_exchange_single_rank(tmp_path):
     """The exchange behind the C ABI (vps_comm_create / vps_spectrum_zimages / vps_allreduce_shells: RCCL loaded by the
     library, grouped ncclSend / ncclRecv per kz chunk on its own stream, events against the context's stream, ncclAllReduce of
     the float64 / uint64 accumulators) on the one GPU of the test box: a one-rank communicator made from a unique id, no
-    torch.distributed involved.  Velocity (three components per launch) and energy against the oracle, twice each."""
+    torch.distributed involved.  Velocity (three components per launch) and energy against the oracle, twice each; the
+    two-slot workspace formula; the exchange timing kinds; and an injected ncclSend failure in the middle of a group (error
+    reported, group closed, the next call correct)."""
     import torch.multiprocessing as mp
     from vpower import synth
     N, Np = 128, 200000
@@ -159,7 +187,7 @@ def test_library_rccl_exchange_single_rank(tmp_path):
     vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
     v, m = orc.vm_from_vec_grid(orc.deposit_to_grid_fast(vec, pos, N, 1.0), 1.0 / N, zero_empty=True)
     tabs = np.load(tmp_path / "tab_lib.npy")
-    for i, q in enumerate(("velocity", "velocity", "energy", "energy")):
+    for i, q in enumerate(("velocity", "velocity", "energy", "energy", "velocity")):     # (the last one: after the injected failure)
         ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, 1.0 / N, q)
         ref[:, 1] /= np.where(ref[:, 0] > 0, 4 * np.pi * ref[:, 0] ** 2, 1)
         assert np.array_equal(tabs[i][:, 3], ref[:, 3])
@@ -315,3 +343,45 @@ def test_bench_field_parallel_step_on_shared_gpu(tmp_path, world, N):
             assert np.array_equal(tab[:, 3], ref[:, 3])
             assert np.allclose(tab[:, 2], ref[:, 2], rtol=2e-5, atol=0)
             assert np.allclose(tab[:, 1], ref[:, 1], rtol=2e-5, atol=0)
+
+
+@pytest.mark.parametrize("world,transport", [(2, "torch"), (4, "torch"), (1, "library")])
+def test_bench_main_several_ranks_rehearsal(tmp_path, world, transport):
+    """`python bench.py --gpus N` as the driver starts it (bench.main's own self-spawn: a torch.distributed.run child), at a
+    rehearsal grid on the one GPU of the test box: 2 and 4 gloo ranks sharing the device (torch transport: all_to_all_single
+    staged through the host), and the library transport (RCCL inside libvps_hip.so; RCCL cannot put two ranks on one device,
+    so one rank with forced collectives).  The line must report the SLAB decomposition as `value` -- what BASELINE.json's C4
+    names -- with, inside `config`, the transport, chunk count, row fraction, both decompositions' step times and the
+    exchange diagnosis (kernel_ms, exchange_ms, exposed_exchange_ms: max over ranks); the field-parallel split under
+    `alternative`, its tables equal to the slab run's; parity against the oracle asserted inside."""
+    import json
+    import subprocess
+    env = dict(os.environ, VPS_BENCH_GRID="128", VPS_BENCH_PARTICLES="300000", VPS_A2A_CHUNKS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if transport == "library":
+        env.update(VPS_BENCH_TRANSPORT="library", VPS_FORCE_COLLECTIVES="1")
+    else:
+        env.update(VPS_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-other-configs", "--profile-steps", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == world and d["value"] > 0 and d["scaling"] == "strong" and "REHEARSAL" in cfg["deviation"]
+    assert cfg["decomposition"] == "slab" and cfg["chunks"] == 4 and cfg["chunks_in_flight"] == 2
+    assert ("gloo" in cfg["transport"]) if transport == "torch" else ("libvps_hip.so" in cfg["transport"])
+    assert abs(cfg["ms_per_step_slab"] - d["ms_per_step"]) < 1e-9
+    ex = cfg["slab_exchange"]
+    assert ex == d["slab_exchange"]
+    for key in ("kernel_ms", "exchange_ms", "exposed_exchange_ms"):
+        assert ex[key] >= 0.0
+    assert ex["kernel_ms"] > 0 and ex["exchange_ms"] > 0
+    assert d["full_size_check"]["nsample_exact"]
+    if world > 1:
+        assert 0 < cfg["exchange_row_fraction"] <= 1.0 and "max over the %d ranks" % world in ex["over"]
+        assert d["parity"]["nsample_equal"] and d["parity"]["psum_max_rel"] < 2e-5
+        alt = d["alternative"]
+        assert alt["decomposition"] == "fields" and alt["vs_own_tables"]["nsample_equal"] and alt["vs_own_tables"]["psum_max_rel"] < 2e-5
+        assert abs(cfg["ms_per_step_fields"] - alt["ms_per_step"]) < 1e-9

@@ -306,6 +306,43 @@ def test_general_binning_path_matches_fast_path(K, N, L):
         assert np.allclose(out[False][:, 2], ref[:, 2], rtol=PSUM_RTOL, atol=0)
 
 
+@pytest.mark.parametrize("N,L", [(32, 1.0), (64, 2.5), (256, 1.0), (512, 1.0)])
+def test_integer_shells_equal_float64_shells(K, N, L):
+    """Mirrored-kx binning with INTEGER shells (fft.hip FASTMODE 2: ix^2 + iy^2 + iz^2 against ceil(thr / k2[1])) -- taken
+    wherever vps_set_binning finds no threshold on an integer multiple of k2[1], which covers both reference flavours (edges at
+    half-integer multiples of 2 pi / L, interp.py:1472-1473 / script:178-180) -- decides every mode exactly like the float64
+    comparison of k^2 sums: same counts bit for bit as the float64 path AND as the oracle's np.histogram.  Edges ON integer
+    multiples (modes sitting exactly on shell edges: float64 rounding decides) must fall back to the float64 path."""
+    from vpower import device, _ffi
+    rng = np.random.default_rng(N + 7)
+    fields = [K.to_device(rng.standard_normal((N, N, N)).astype(np.float32)) for _ in range(3)]
+    f64 = [f.cpu().numpy().astype(np.float64) for f in fields]
+    P = orc.vector_power(*f64, L, N)
+    kf = 2 * np.pi / L
+    cases = [("library", None, None, None, 2), ("script", None, None, None, 2), ("library", None, None, 0.37 * kf, 2),
+             ("library", 1.5 * kf, None, kf, 1),        # edges at 1, 2, 3 ... kf: thresholds ON integers
+             ("library", 2.0 * kf, 0.4 * np.pi * N / L, 2.0 * kf, 1)]
+    for flavour, kmin, kmax, kres, want_mode in cases:
+        tabs = {}
+        for no_int in (None, 1):
+            _ffi.set_option("no_int_binning", no_int)
+            try:
+                pipe = device.PowerPipeline(N, L, kernels=K, comm=device.SlabComm(enabled=False), flavour=flavour,
+                                            kmin=kmin, kmax=kmax, kres=kres)
+                pipe.prepare()
+                mode = K.binning_mode()
+                assert mode == (1 if no_int else want_mode), (flavour, kmin, kres, mode)
+                tabs[no_int] = pipe.finish(*pipe.accumulate(fields))
+            finally:
+                _ffi.set_option("no_int_binning", None)
+        ref = orc.spectrum_table(P, L, N, flavour, kmin=kmin, kmax=kmax, kres=kres)
+        for t in tabs.values():
+            assert np.array_equal(t[:, 3], ref[:, 3])                        # Nsample: bit exact, both paths
+            assert np.allclose(t[:, 2], ref[:, 2], rtol=PSUM_RTOL, atol=0)
+        assert np.array_equal(tabs[None][:, 3], tabs[1][:, 3])
+        assert np.allclose(tabs[None][:, 2], tabs[1][:, 2], rtol=1e-6, atol=0)
+
+
 @pytest.mark.parametrize("N", [16, 32, 64, 128])
 def test_nsample_golden(K, N):
     from vpower import device

@@ -24,7 +24,7 @@ def test_abi_exports_every_declared_symbol():
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vps_version() == 4
+    assert lib.vps_version() == _ffi.ABI_VERSION == int(re.search(r"#define VPS_ABI_VERSION (\d+)", hdr).group(1))
     # option switches: explicit, process-wide, unknown names refused (the library never reads the environment)
     assert lib.vps_set_option(b"nn_kappa", 1.3) == 0 and lib.vps_get_option(b"nn_kappa", 0.0) == 1.3
     assert lib.vps_set_option(b"nn_kappa", float("nan")) == 0 and lib.vps_get_option(b"nn_kappa", 1.15) == 1.15

@@ -181,3 +181,22 @@ def test_unfolded_oracle_equals_reference_on_8_mpi_ranks(tag):
     assert np.allclose(tab[:, 1], ref[:, 1], rtol=2e-6)
     one = golden("script_%s.npz" % tag.split("_")[0])["Pk"]            # the reference's own 1-rank run
     assert np.array_equal(one[:, 3], ref[:, 3]) and np.allclose(one[:, 2], ref[:, 2], rtol=1e-6)
+
+
+@pytest.mark.parametrize("N,Np,workers", [(32, 30000, 3), (48, 50000, 8)])
+def test_allcores_oracle_equals_the_one_core_oracle(N, Np, workers):
+    """oracle/allcores.py -- the oracle's NGP step spread over the host's cores (one process per x-slab for gridding, |F|^2 and
+    the two histograms; threaded transforms), what bench.py times as `cpu_baseline_allcores` -- gives the one-core oracle's
+    tables: shell counts exactly, shell sums to float64 rounding (partial histograms are added in slab order)."""
+    from oracle import allcores
+    from oracle import vps_oracle as orc
+    pos, vel, mass, dens = synth(7, Np, 1.0)
+    quantities = ("velocity", "momentum", "energy")
+    tabs, t = allcores.ngp_tables(quantities, "library", N, 1.0, pos, vel, dens, workers)
+    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
+    v, m = orc.vm_from_vec_grid(orc.deposit_to_grid(vec, pos, N, 1.0), 1.0 / N, zero_empty=True)
+    for q in quantities:
+        ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, 1.0 / N, q)
+        assert np.array_equal(tabs[q][:, 0], ref[:, 0]) and np.array_equal(tabs[q][:, 3], ref[:, 3])
+        assert np.allclose(tabs[q][:, 2], ref[:, 2], rtol=1e-11, atol=0) and np.allclose(tabs[q][:, 1], ref[:, 1], rtol=1e-11, atol=0)
+    assert set(t) == {"gridding", "spctrm_velocity", "spctrm_momentum", "spctrm_energy", "total"}

@@ -66,5 +66,9 @@ for cfg, m in fam.items():
         hits = [v["hbm_bytes_corrected"] for k, v in summary.items() if k.startswith(prefix)]
         if hits:
             traffic[cfg][key] = max(hits)
+# the kernel sources the counters belong to: bench.py drops the figure when they have changed since
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+traffic["kernel_sources_sha16"] = bench.kernel_sources_sha16()
 json.dump(traffic, open(dst + "_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
