@@ -29,9 +29,13 @@
 //   VPS_PENCIL_NOSTORE  pencil kernel without its global stores      VPS_ABL_NOZERO / VPS_ABL_NOSCATTER  ... without the
 //   VPS_ABL_NOFFT       ... without transform, image and stores      accumulator's zero-fill / the LDS adds
 //   VPS_ABL_X_NOATOMIC / VPS_ABL_X_NOBIN   x pass without the LDS shell atomics / without the shell search and binning
+#ifndef VPS_Y_ST16
+#define VPS_Y_ST16 1   // wide y pass: 16-byte stores (2048^3 launch 12.56 -> 12.10 ms; 0 restores the 8-byte epilogue)
+#endif
 namespace {
 
 typedef float2 cf;
+typedef float vps_f4 __attribute__((ext_vector_type(4)));
 
 // (written on whole (re, im) pairs: the compiler then keeps a complex value in one aligned register pair and maps these
 // onto v_pk_add / v_pk_mul / v_pk_fma with operand-select modifiers; the component-wise form was re-vectorised across
@@ -383,10 +387,25 @@ __device__ __forceinline__ int tridx(int k, int t) {
 template <int NC, int L, int RL, int R>
 __device__ __forceinline__ void lds_load_stage(cf (&v)[RL], const cf* line, int l) {
   constexpr int NB = RL / R;
+  // Where every stride is a multiple of the 32 elements between pad slots, padidx(l + c) = padidx(l) + c + c / 32 exactly: ONE
+  // lane-dependent address and immediate offsets.  (Left to the compiler each of the RL addresses cost four VALU operations --
+  // or, shift, and, add3 -- a fifth of the instructions of a 2048-point transform.)
+  if constexpr ((L % 32 == 0) && ((NC / R) % 32 == 0)) {
+    const cf* base = line + padidx<NC>(l);
 #pragma unroll
-  for (int m = 0; m < NB; ++m) {
+    for (int m = 0; m < NB; ++m) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[m * R + r] = line[padidx<NC>(l + L * m + r * (NC / R))];
+      for (int r = 0; r < R; ++r) {
+        const int c = L * m + r * (NC / R);
+        v[m * R + r] = base[c + (c >> 5)];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[m * R + r] = line[padidx<NC>(l + L * m + r * (NC / R))];
+    }
   }
 }
 
@@ -430,9 +449,11 @@ __device__ __forceinline__ cf rot16(cf v) {
 template <int NC, int L, int RL, int R, int NS>
 struct RegTwiddles {
   static constexpr int NB = RL / R;
-  // the step of the twiddle angle from one butterfly of a lane to the next, in 16ths of a turn per unit of r
-  static constexpr bool OK = (L * (NB - 1) < NS) && ((16 * L) % (NS * R) == 0);
-  static constexpr int STEP16 = OK ? (16 * L) / (NS * R) : 0;
+  // SAME: L is a multiple of NS, every butterfly of a lane has the same twiddle index l % NS.  Otherwise the index moves by L
+  // per butterfly without wrapping, and the angle by STEP16 sixteenths of a turn per unit of r.
+  static constexpr bool SAME = (L % NS == 0);
+  static constexpr bool OK = SAME || ((L * (NB - 1) < NS) && ((16 * L) % (NS * R) == 0));
+  static constexpr int STEP16 = (OK && !SAME) ? (16 * L) / (NS * R) : 0;
 };
 template <int NC, int L, int RL, int R, int NS, int M, int RR>
 __device__ __forceinline__ void twiddle_reg_apply(cf (&v)[RL], const cf* twr) {
@@ -456,6 +477,22 @@ __device__ __forceinline__ void load_stage_twiddles(cf (&twr)[R - 1], const cf* 
   for (int r = 1; r < R; ++r) twr[r - 1] = tw_global[(r - 1) * NS + l % NS];
 }
 
+// Can padidx(j0 + r NS) be formed as padidx(j0) + (r NS + r NS / 32) for every butterfly of a radix-R stage?  j0 = A + k with A a
+// multiple of NS R and k < NS; the split is exact iff (j0 mod 32) + (r NS mod 32) < 32 -- checked here for every residue.
+template <int R, int NS>
+constexpr bool pad_split_ok() {
+  int g = NS * R;
+  while (32 % g != 0 && g > 1) {   // gcd(NS R, 32) for the power-of-two cases; anything else: no split
+    if (g % 2) return false;
+    g /= 2;
+  }
+  if (32 % g != 0) return false;
+  for (int a = 0; a < 32; a += g)
+    for (int k = 0; k < NS && k < 32; ++k)
+      for (int r = 0; r < R; ++r)
+        if ((a + k) % 32 + (r * NS) % 32 >= 32) return false;
+  return (NS & (NS - 1)) == 0 && (R & (R - 1)) == 0;
+}
 template <int NC, int L, int RL, int R, int NS>
 __device__ __forceinline__ void lds_store_stage(const cf (&v)[RL], cf* line, int l) {
   constexpr int NB = RL / R;
@@ -464,8 +501,14 @@ __device__ __forceinline__ void lds_store_stage(const cf (&v)[RL], cf* line, int
     const int j = l + L * m;
     const int k = j % NS;
     const int j0 = (j - k) * R + k;
+    if constexpr (pad_split_ok<R, NS>()) {   // one lane-dependent address per butterfly, immediate offsets (see lds_load_stage)
+      cf* base = line + padidx<NC>(j0);
 #pragma unroll
-    for (int r = 0; r < R; ++r) line[padidx<NC>(j0 + r * NS)] = v[m * R + r];
+      for (int r = 0; r < R; ++r) base[r * NS + ((r * NS) >> 5)] = v[m * R + r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) line[padidx<NC>(j0 + r * NS)] = v[m * R + r];
+    }
   }
 }
 
@@ -517,8 +560,10 @@ __device__ __forceinline__ void rows_transpose4(float& x0, float& x1, float& x2,
 // Runs stages 1.. (stage 0 inputs already in v).  On return v holds the spectrum:
 // v[m*RLAST + r] = F[l + L*m + r*NC/RLAST].  L lanes per line (default: the plan's; the persistent transposing pass
 // of the longest lines runs a line on half as many lanes with twice the points each).
-template <int NC, int L, bool WAVE, bool TWREG = false>
-__device__ __forceinline__ void fft_from_regs_l(cf (&v)[NC / L], cf* line, const cf* tw, int l, const cf* twr = nullptr) {
+// TWREG: bit 0 -- the twiddles of stage 1 come from registers (twr1), bit 1 -- those of stage 2 (twr); see twiddle_butterfly_reg
+template <int NC, int L, bool WAVE, int TWREG = 0>
+__device__ __forceinline__ void fft_from_regs_l(cf (&v)[NC / L], cf* line, const cf* tw, int l, const cf* twr = nullptr,
+                                                const cf* twr1 = nullptr) {
   typedef PlanInfo<NC> PI;
   constexpr int RL = NC / L;
   static_assert(RL % PI::R0 == 0 && RL % PI::R1 == 0 && RL % PI::R2 == 0, "radix must divide RL");
@@ -527,7 +572,10 @@ __device__ __forceinline__ void fft_from_regs_l(cf (&v)[NC / L], cf* line, const
     lds_store_stage<NC, L, RL, PI::R0, 1>(v, line, l);
     exchange_sync<WAVE>();
     lds_load_stage<NC, L, RL, PI::R1>(v, line, l);
-    twiddle_butterfly<NC, L, RL, PI::R1, PI::NS1>(v, tw, l);
+    if constexpr ((TWREG & 1) != 0)
+      twiddle_butterfly_reg<NC, L, RL, PI::R1, PI::NS1>(v, twr1);
+    else
+      twiddle_butterfly<NC, L, RL, PI::R1, PI::NS1>(v, tw, l);
     if constexpr (PI::R2 > 1) {
       if constexpr (swap_exchange2<NC, L, WAVE>()) {
 #pragma unroll
@@ -548,14 +596,14 @@ __device__ __forceinline__ void fft_from_regs_l(cf (&v)[NC / L], cf* line, const
         exchange_sync<WAVE>();
         lds_load_stage<NC, L, RL, PI::R2>(v, line, l);
       }
-      if constexpr (TWREG)
+      if constexpr ((TWREG & 2) != 0)
         twiddle_butterfly_reg<NC, L, RL, PI::R2, PI::NS2>(v, twr);
       else
         twiddle_butterfly<NC, L, RL, PI::R2, PI::NS2>(v, tw + PI::TW1, l);
     }
   }
 }
-template <int NC, bool WAVE = false, bool TWREG = false>
+template <int NC, bool WAVE = false, int TWREG = 0>
 __device__ __forceinline__ void fft_from_regs(cf (&v)[PlanInfo<NC>::RL], cf* line, const cf* tw, int l, const cf* twr = nullptr) {
   fft_from_regs_l<NC, PlanInfo<NC>::L, WAVE, TWREG>(v, line, tw, l, twr);
 }
@@ -679,7 +727,6 @@ __device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf*
 
 // The same for 8-line tiles with 16-byte stores: a thread owns the lines (tt, tt + 1) of a mode pair, so a 64-byte output
 // segment leaves as four dwordx4 stores instead of eight dwordx2 (half the store instructions of the pencil kernel's epilogue).
-typedef float vps_f4 __attribute__((ext_vector_type(4)));
 template <int NC, int T, int NT, bool PLAIN = false>
 __device__ __forceinline__ void r2c_store_tile16(const cf* buf, int tid, const cf* __restrict__ tw_r2c, cf* out,
                                                  long long out_ok, cf* nyq) {
@@ -942,6 +989,28 @@ __global__ void __launch_bounds__(TG* L, (NC == 1024 ? 4 : 1))
       if (h == 1 && ntiles - tile > gridDim.x) load_line(v0, tile + gridDim.x, fresh(tid), 0);
       __syncthreads();
       constexpr int IT = (NC / 2) * T / NT;
+#if VPS_Y_ST16
+      // 16-byte stores: a lane owns the lines (tt, tt + 1) of a row, a 128-byte segment leaves as eight dwordx4 stores instead of
+      // sixteen dwordx2 (the pencil kernel's epilogue gained 7 % from the same change: these epilogues are bound by store ISSUE)
+      if (((p.out_ok | p.A) & 1) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0) {   // (uniform)
+        static_assert(IT % 2 == 0, "whole rounds of line pairs");
+#pragma unroll 4
+        for (int i = 0; i < IT / 2; ++i) {
+          const int idx = tid2 + i * NT;
+          const int tt = (idx % (T / 2)) * 2, kk = idx / (T / 2), k = kk + h * (NC / 2);
+          if (a0 + tt < p.A && min(k, NC - k) <= kc) {
+            const cf va = buf[tridx<T>(kk, tt)], vb = buf[tridx<T>(kk, tt + 1)];
+            const long long o = (long long)packed_row(k, NC, pt.y) * p.out_ok + tt;
+            const vps_f4 val = {va.x, va.y, vb.x, vb.y};
+            if constexpr (NTEMP)
+              __builtin_nontemporal_store(val, reinterpret_cast<vps_f4*>(&out[o]));
+            else
+              *reinterpret_cast<vps_f4*>(&out[o]) = val;
+          }
+        }
+        continue;
+      }
+#endif
 #pragma unroll 4
       for (int i = 0; i < IT; ++i) {
         const int idx = tid2 + i * NT;
@@ -974,6 +1043,7 @@ struct PencilParams {
   const unsigned* records;   // (1 + 4) 32-bit words per particle, sorted by pencil
   const unsigned* start;     // [npencils + 1]
   int N, nx, nby;            // grid, slab rows, pencils per x row (N / TP)
+  unsigned npencils;         // pencils of the launch (the persistent form walks them: slot, slot + gridDim.x, ...)
   int ncomp;
   int chan[3];               // record channel (0..2) feeding component c
   int divide;                // 1: v = q / rho (0 where rho == 0);  0: p = q * vol
@@ -1022,6 +1092,30 @@ constexpr int pencil_lanes() {
 #ifndef VPS_ST16_ALL
 #define VPS_ST16_ALL 0    // 1: 16-byte stores for 16-line pencils too (experiment)
 #endif
+// 1024-point lines on the plan's 64 lanes (the 2048^3 grid): the twiddles of both later stages depend on the lane alone and
+// CAN stay in registers for the whole kernel (7 + 7 values; the second butterfly of stage 2 by constant 16th-root rotations:
+// 28 of the 32 LDS reads per lane and transform that are not data) -- measured slower here, unlike in the x pass, see below.
+#ifndef VPS_PENCIL_PERSIST
+#define VPS_PENCIL_PERSIST 0   // 1: persistent workgroups with the next pencil's records prefetched (see the kernel).  Measured at C4,
+                               // twice (rounds 2 and 4, the second time with the bounds, cells and first values of the next pencil
+                               // requested behind the last transform and the twiddles staged once): vector launch 27.3 against 26.5 ms,
+                               // energy 13.2 against 10.3 -- with or without holding every other workgroup back.  What the hardware
+                               // dispatcher gives for free -- workgroups of a CU out of step with each other -- is worth more than the
+                               // two dependent trips to HBM a fresh workgroup starts with.
+#endif
+#ifndef VPS_PENCIL_STAGGER
+#define VPS_PENCIL_STAGGER 0   // PERSIST: s_sleep(127) rounds by which the second workgroup of every CU starts late
+#endif
+#ifndef VPS_PENCIL_TWREG
+#define VPS_PENCIL_TWREG 0     // bit 0: stage 1, bit 1: stage 2.  Measured at C4 (vector / energy launch, ms): 0: 26.5 / 10.4;
+                               // 1: 27.8 / 11.8; 2: 27.2 / 12.1; 3 (7 registers spilled): 27.1 / 13.3 -- the LDS reads they save
+                               // cost less than the registers they take (80 -> 104..128 VGPRs): off
+#endif
+template <int NC>
+constexpr int pencil_twreg() {
+  typedef PlanInfo<NC> PI;
+  return (NC == 1024 && pencil_lanes<NC>() == 64 && PI::R1 == 8 && PI::R2 == 8) ? (VPS_PENCIL_TWREG) : 0;
+}
 template <int NC, int TP, bool ENERGY = false>
 __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()) pencil_fft_z_kernel(const PencilParams p) {
   typedef PlanInfo<NC> PI;
@@ -1035,10 +1129,11 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
   float* acc = reinterpret_cast<float*>(smem_raw);
   cf* buf = reinterpret_cast<cf*>(acc);
   cf* tw_lds = reinterpret_cast<cf*>(acc + SHARED);
+  constexpr int TWR = pencil_twreg<NC>();
 #ifdef VPS_PENCIL_TW_GLOBAL
   constexpr bool TWL = false;
 #else
-  constexpr bool TWL = PI::TWLDS;
+  constexpr bool TWL = PI::TWLDS && TWR != 3;
 #endif
   const cf* tw = TWL ? tw_lds : p.tw_stage;
 
@@ -1047,21 +1142,30 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
   // Pencils narrower than a 128-byte output line (TP < 16): the 16/TP pencils that share output lines are consecutive
   // pencil numbers; run them on ONE XCD, close in time, so that its L2 merges their partial-line writes (same map as
   // fft_transpose_pass: hardware block h = 8 s + x handles logical pencil G*(8*(s/G) + x) + s%G)
-  unsigned pencil = blockIdx.x;
   constexpr unsigned GP = (TP < 16) ? 16 / TP : 1;
-  if constexpr (GP > 1) {
-    const unsigned span = 8 * GP;
-    if (pencil / span < gridDim.x / span) {   // whole groups only; the tail keeps the identity map
-      const unsigned base = (pencil / span) * span, h = pencil % span;
-      pencil = base + GP * (h % 8) + (h / 8);
+  auto map_slot = [&](unsigned slot) -> unsigned {
+    if constexpr (GP > 1) {
+      const unsigned span = 8 * GP;
+      if (slot / span < p.npencils / span) {   // whole groups only; the tail keeps the identity map
+        const unsigned base = (slot / span) * span, h = slot % span;
+        return base + GP * (h % 8) + (h / 8);
+      }
     }
-  }
-  const int x = pencil / p.nby, y0 = (pencil % p.nby) * TP;
-  const unsigned s = p.start[pencil], e = p.start[pencil + 1];
-  // more than two particles per cell on average: hot cells are likely, take the native atomics (vps_lds_add)
-  const bool crowded = (e - s) > 2u * (unsigned)ACC;
+    return slot;
+  };
+  // PERSIST (VPS_PENCIL_PERSIST): the workgroup walks pencil slots blockIdx.x, + gridDim.x, ... -- the twiddles are staged
+  // once, and the bucket bounds, cells and first values of the NEXT pencil are requested behind the last component's
+  // transform, so that a pencil no longer begins with two dependent trips to HBM (bounds, then records) and a table copy.
+  constexpr bool PERSIST = VPS_PENCIL_PERSIST != 0;
+  unsigned slot = blockIdx.x;
+  unsigned pencil = map_slot(slot);
+  unsigned s = p.start[pencil], e = p.start[pencil + 1];
+  unsigned s_n = 0, e_n = 0, pencil_n = 0;
   if constexpr (TWL)
     for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
+  cf twr1[(TWR & 1) ? (PI::R1 - 1) : 1], twr2[(TWR & 2) ? (PI::R2 - 1) : 1];
+  if constexpr ((TWR & 1) != 0) load_stage_twiddles<NC, L, RL, PI::R1, PI::NS1>(twr1, p.tw_stage, l);
+  if constexpr ((TWR & 2) != 0) load_stage_twiddles<NC, L, RL, PI::R2, PI::NS2>(twr2, p.tw_stage + PI::TW1, l);
   // What a CELL needs besides the sums -- 1/rho (velocity), the running sum of (rho v_c)^2 (energy) -- is kept per RECORD:
   // every record of a cell reads the cell's total from the accumulator and carries the same value.  A per-cell table would
   // be RL register pairs per lane next to the RL transform registers (it was: the kernel then fit four waves per SIMD only
@@ -1075,6 +1179,8 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
   unsigned rloc[KR];
   float rval[KR];
   float rrec[KR];   // 1/rho of the record's cell (velocity) / sum over components of (rho v_c)^2 of its cell (ENERGY)
+  unsigned rloc_n[PERSIST ? KR : 1];
+  float rval_n[PERSIST ? KR : 1];
   auto fetch = [&](int word) {   // record word 1..3: rho v_c, 4: rho
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
@@ -1086,12 +1192,31 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
   for (int k = 0; k < KR; ++k) {
     const unsigned j = s + tid + k * NT;
     rloc[k] = (j < e) ? p.records[(size_t)j * 5] : 0xffffffffu;
-    rrec[k] = 1.f;
   }
   const bool divide = !ENERGY && p.divide;
   fetch(divide ? 4 : 1 + p.chan[0]);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int R0 = PI::R0, NB0 = RL / R0;
+#if VPS_PENCIL_STAGGER
+  // the two workgroups of a CU start together and would stay in step (both accumulating, both storing): hold every other one back
+  if (PERSIST && (blockIdx.x / (gridDim.x / 2)) != 0)
+    for (int i = 0; i < VPS_PENCIL_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+ for (;;) {   // (one pass per pencil; a single pass unless PERSIST)
+  if constexpr (PERSIST) {
+    __syncthreads();   // the previous pencil's transposed image is consumed
+    const unsigned nxt = slot + gridDim.x;
+    if (nxt < p.npencils) {     // bounds of the next pencil: needed at the END of this pass
+      pencil_n = map_slot(nxt);
+      s_n = p.start[pencil_n];
+      e_n = p.start[pencil_n + 1];
+    }
+  }
+  const int x = pencil / p.nby, y0 = (pencil % p.nby) * TP;
+  // more than two particles per cell on average: hot cells are likely, take the native atomics (vps_lds_add)
+  const bool crowded = (e - s) > 2u * (unsigned)ACC;
+#pragma unroll
+  for (int k = 0; k < KR; ++k) rrec[k] = 1.f;
   const unsigned tail0 = s + tid + KR * NT;   // this thread's first record beyond the register-resident ones
   if (divide) {
     for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
@@ -1217,7 +1342,20 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
     for (int i = 0; i < RL; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y));
     if (v[0].x != 1.2345e30f) continue;
 #endif
-    fft_from_regs_l<NC, L, WSYNC>(v, buf + tc * PI::PITCH, tw, lc);
+    if constexpr (PERSIST) {
+      // last round: the records of this pencil are done with -- request the next pencil's cells and first values now, they
+      // land behind this transform and its stores
+      if (c + 1 == nround && slot + gridDim.x < p.npencils) {
+        const int w0 = divide ? 4 : 1 + p.chan[0];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+          const unsigned j = s_n + tid + k * NT;
+          rloc_n[k] = (j < e_n) ? p.records[(size_t)j * 5] : 0xffffffffu;
+          if (j < e_n) rval_n[k] = __uint_as_float(p.records[(size_t)j * 5 + w0]);
+        }
+      }
+    }
+    fft_from_regs_l<NC, L, WSYNC, TWR>(v, buf + tc * PI::PITCH, tw, lc, twr2, twr1);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < RL; ++i) buf[tridx<TP>(out_index_l<NC, L>(lc, i), tc)] = v[i];
@@ -1235,6 +1373,18 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
     else
       r2c_store_tile<NC, TP, NT, false, PLAIN>(buf, tidc, p.tw_r2c, out, N, nyq, TP);
   }
+  if constexpr (!PERSIST) break;
+  slot += gridDim.x;
+  if (slot >= p.npencils) break;
+  pencil = pencil_n;
+  s = s_n;
+  e = e_n;
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    rloc[k] = rloc_n[PERSIST ? k : 0];
+    rval[k] = rval_n[PERSIST ? k : 0];
+  }
+ }
 }
 
 // (A wave-private form -- every wave scans all records of the pencil, keeps those of its own line(s) and runs zero-fill, LDS
@@ -1264,7 +1414,7 @@ size_t pencil_lds_bytes() {
   typedef PlanInfo<NC> PI;
   constexpr int PENCIL_TP = pencil_tp<NC>();
   constexpr int ACC = PENCIL_TP * 2 * NC, LINES = PENCIL_TP * PI::PITCH * 2;
-  return (size_t)(ACC > LINES ? ACC : LINES) * sizeof(float) + (size_t)PI::TWL * sizeof(cf);
+  return (size_t)(ACC > LINES ? ACC : LINES) * sizeof(float) + (size_t)(pencil_twreg<NC>() == 3 ? 0 : PI::TWL) * sizeof(cf);
 }
 
 template <int NC>
@@ -1277,9 +1427,18 @@ int launch_pencil(vps_ctx* ctx, const PencilParams& p, long long npencils) {
   if (lds > 64 * 1024)
     VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PencilParams pp = p;
+  pp.npencils = (unsigned)npencils;
+  long long grid = npencils;
+  if (VPS_PENCIL_PERSIST) {
+    long long per_cu = (long long)(ctx->lds_per_cu / (lds ? lds : 1));
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const long long want = (long long)ctx->num_cu * per_cu;
+    if (grid > want) grid = want;
+  }
   {
     vps_launch_timer tm(ctx, VPS_K_FFT_Z);
-    hipLaunchKernelGGL(kern, dim3((unsigned)npencils), dim3(PENCIL_TP * pencil_lanes<NC>()), lds, ctx->stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PENCIL_TP * pencil_lanes<NC>()), lds, ctx->stream, pp);
   }
   VPS_HIP_CHECK(ctx, hipGetLastError());
   return VPS_OK;
@@ -1489,6 +1648,23 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, (x_twreg<NC, FASTMODE, SEG
   auto load_line = [&](cf (&v)[RL], int c, int l) {   // l: the lane index (callers inside loops pass an opaque copy)
     constexpr int R = PI::R0, NB = RL / R;
     const cf* base = (c == 0 ? p.in : (c == 1 ? p.in1 : p.in2)) + lrow * p.seglen;
+    if constexpr (!SEG && (L % 64 == 0)) {
+      // A wave holds lanes of ONE line: whether the line is read at all is wave-uniform -- one scalar branch around the RL loads
+      // instead of an exec-mask branch around every pair of them (which is what `live ? load : 0` per element compiles to).
+      if (__builtin_amdgcn_readfirstlane((int)live)) {
+#pragma unroll
+        for (int m = 0; m < NB; ++m)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const double raw = __builtin_nontemporal_load(reinterpret_cast<const double*>(&base[l + L * m + r * (NC / R)]));
+            v[m * R + r] = *reinterpret_cast<const cf*>(&raw);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < RL; ++i) v[i] = make_float2(0.f, 0.f);
+      }
+      return;
+    }
     if constexpr (SEG && (L % 64 == 0)) {
       // A wave holds lanes of ONE line here, so the line's base is wave-uniform; and with power-of-two segments of at least L
       // elements, element x = l + xr (xr = L m + r NC/R, a multiple of L) sits in segment xr >> seg_shift at offset
@@ -1565,7 +1741,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, (x_twreg<NC, FASTMODE, SEG
     const float wyz_cur = wyz;
     if constexpr (MODE != 0) {
       exchange_sync<WSYNC>();  // previous tile's readers are done with the line buffers
-      fft_from_regs<NC, WSYNC, TWREG>(v, line, tw, l, twr);
+      fft_from_regs<NC, WSYNC, (TWREG ? 2 : 0)>(v, line, tw, l, twr);
     }
     if constexpr (MODE == 1) {
       if (live_cur) {
@@ -1612,7 +1788,7 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, (x_twreg<NC, FASTMODE, SEG
         }
 #endif
         exchange_sync<WSYNC>();  // previous readers are done with the line buffers
-        fft_from_regs<NC, WSYNC, TWREG>(v, line, tw, lc, twr);
+        fft_from_regs<NC, WSYNC, (TWREG ? 2 : 0)>(v, line, tw, lc, twr);
 #pragma unroll
         for (int i = 0; i < RL; ++i) {
           const float a = v[i].x * v[i].x + v[i].y * v[i].y;
@@ -1642,8 +1818,15 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, (x_twreg<NC, FASTMODE, SEG
         lw = (L & (L - 1)) == 0 ? (lw & (L - 1)) : lw % L;
 #pragma unroll
         for (int i = 0; i < RL; ++i) {
-          const int k = out_index<NC>(lw, i);
-          pw[k + k / CH] = pacc[i];
+          // k = lw + c with c a multiple of CH wherever the plan's lanes are (power-of-two plans): k / CH = lw / CH + c / CH
+          constexpr int RLAST = LastRadix<NC>::R;
+          const int c = L * (i / RLAST) + (i % RLAST) * (NC / RLAST);
+          if constexpr ((L % CH == 0) && ((NC / RLAST) % CH == 0)) {
+            pw[(lw + lw / CH) + c + c / CH] = pacc[i];
+          } else {
+            const int k = out_index<NC>(lw, i);
+            pw[k + k / CH] = pacc[i];
+          }
         }
       }
       exchange_sync<WSYNC>();
