@@ -858,25 +858,36 @@ def cpu_baseline_legs(cfg):
         # the volume, scripts/parallel_optimized.py:201-491 under `mpiexec -n R`): oracle/allcores.py -- one process per x-slab for
         # gridding, |F|^2 and both histograms, threaded transforms -- on the SAME sample as the one-core leg.  A child process of its
         # own: it forks its workers, and they must not inherit this process's GPU state.
-        nthr = min(os.cpu_count() or 1, 128, Nc // 2)
-        cmd = [sys.executable, os.path.join(ROOT, "oracle", "allcores.py"), "--grid", str(Nc), "--particles", str(Npc),
-               "--workers", str(nthr), "--quantities", ",".join(quantities), "--flavour", flavour,
-               "--seed", str(synth.BASE_SEED + 200 + off), "--lognormal", str(int(lognormal))]
+        # (two worker counts: process start-up and shared-memory page faults grow with the count, the slabs shrink with it --
+        #  which one wins depends on the host; the faster run is the baseline, both are listed)
+        ncpu = os.cpu_count() or 1
+        tries, runs = sorted({max(1, min(ncpu, Nc // 2) // 4), max(1, min(ncpu // 2, 128, Nc // 2))}), {}
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-        try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-            t2 = json.loads(r.stdout.strip().splitlines()[-1])
+        for nthr in tries:
+            cmd = [sys.executable, os.path.join(ROOT, "oracle", "allcores.py"), "--grid", str(Nc), "--particles", str(Npc),
+                   "--workers", str(nthr), "--quantities", ",".join(quantities), "--flavour", flavour,
+                   "--seed", str(synth.BASE_SEED + 200 + off), "--lognormal", str(int(lognormal))]
+            try:
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+                runs[nthr] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:      # (the headline must not be lost to the extra CPU leg)
+                runs[nthr] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        good = {k: v for k, v in runs.items() if "seconds" in v}
+        if good:
+            nthr = min(good, key=lambda k: good[k]["seconds"])
+            t2 = good[nthr]
             out["cpu_baseline_allcores"] = {
                 "value": Nc ** 3 * nfields / t2["seconds"], "unit": unit, "cores": nthr, "kind": "port",
                 "sample": "oracle/allcores.py on the one-core leg's sample (%d^3 cells, %d particles): every stage spread over %d worker "
                           "processes by x-slab (gridding, field algebra, |F|^2, both histograms) + threaded 3-D transforms: %s"
                           % (Nc, Npc, nthr, ", ".join("%s %.2fs" % kv for kv in t2["stage_seconds"].items())),
                 "seconds": t2["seconds"], "stage_seconds": t2["stage_seconds"],
+                "seconds_by_workers": {str(k): v.get("seconds", v.get("error")) for k, v in runs.items()},
                 "speedup_over_one_core": t1["total"] / t2["seconds"],
                 "extrapolated_seconds_full_size": t2["seconds"] * scale,
-                "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
-        except Exception as e:      # (the headline must not be lost to the extra CPU leg)
-            out["cpu_baseline_allcores"] = {"skipped": "%s: %s" % (type(e).__name__, str(e)[:200])}
+                "cpu_model": cpu_model(), "host_cores": ncpu}
+        else:
+            out["cpu_baseline_allcores"] = {"skipped": str(runs)}
     elif route != "script":
         Ns, Nps_ = sample_size(route, N, Np)
         pos, vel, _, dens = synth.particles(synth.BASE_SEED + 100 + off, Nps_, L, lognormal)

@@ -29,6 +29,9 @@
 //   VPS_PENCIL_NOSTORE  pencil kernel without its global stores      VPS_ABL_NOZERO / VPS_ABL_NOSCATTER  ... without the
 //   VPS_ABL_NOFFT       ... without transform, image and stores      accumulator's zero-fill / the LDS adds
 //   VPS_ABL_X_NOATOMIC / VPS_ABL_X_NOBIN   x pass without the LDS shell atomics / without the shell search and binning
+#ifndef VPS_Y_EARLY_G1
+#define VPS_Y_EARLY_G1 0   // wide y pass: the second group of lines requested ahead of the first group's transform (experiment)
+#endif
 #ifndef VPS_Y_ST16
 #define VPS_Y_ST16 1   // wide y pass: 16-byte stores (2048^3 launch 12.56 -> 12.10 ms; 0 restores the 8-byte epilogue)
 #endif
@@ -727,9 +730,12 @@ __device__ __forceinline__ void r2c_store_tile(const cf* buf, int tid, const cf*
 
 // The same for 8-line tiles with 16-byte stores: a thread owns the lines (tt, tt + 1) of a mode pair, so a 64-byte output
 // segment leaves as four dwordx4 stores instead of eight dwordx2 (half the store instructions of the pencil kernel's epilogue).
+// zero_behind (uniform): every image element is cleared once it has been read (each is read by exactly one thread), so that the
+// region is an all-zero accumulator again when the epilogue ends -- the next component's dense zero-fill and the barrier behind
+// it move off the critical path into this store-issue-bound loop.
 template <int NC, int T, int NT, bool PLAIN = false>
-__device__ __forceinline__ void r2c_store_tile16(const cf* buf, int tid, const cf* __restrict__ tw_r2c, cf* out,
-                                                 long long out_ok, cf* nyq) {
+__device__ __forceinline__ void r2c_store_tile16(cf* buf, int tid, const cf* __restrict__ tw_r2c, cf* out,
+                                                 long long out_ok, cf* nyq, bool zero_behind = false, const cf* wpre = nullptr) {
   static_assert((NC & 1) == 0 && (T & 1) == 0, "pairs of lines");
   constexpr int H = T / 2;
   constexpr int ITEMS = (NC / 2) * H;
@@ -738,15 +744,28 @@ __device__ __forceinline__ void r2c_store_tile16(const cf* buf, int tid, const c
   for (int i = 0; i < ITEMS / NT; ++i) {
     const int idx = tid + i * NT;
     const int tt = (idx % H) * 2, k = idx / H;
+    const cf zz = make_float2(0.f, 0.f);
     const cf a0 = buf[tridx<T>(k, tt)], a1 = buf[tridx<T>(k, tt + 1)];
+    if (zero_behind) {
+      buf[tridx<T>(k, tt)] = zz;
+      buf[tridx<T>(k, tt + 1)] = zz;
+    }
     if (k == 0) {
       *reinterpret_cast<vps_f4*>(&out[tt]) = vps_f4{a0.x + a0.y, 0.f, a1.x + a1.y, 0.f};
       *reinterpret_cast<vps_f4*>(&nyq[tt]) = vps_f4{a0.x - a0.y, 0.f, a1.x - a1.y, 0.f};
       const cf h0 = buf[tridx<T>(NC / 2, tt)], h1 = buf[tridx<T>(NC / 2, tt + 1)];
+      if (zero_behind) {
+        buf[tridx<T>(NC / 2, tt)] = zz;
+        buf[tridx<T>(NC / 2, tt + 1)] = zz;
+      }
       *reinterpret_cast<vps_f4*>(&out[(long long)(NC / 2) * out_ok + tt]) = vps_f4{h0.x, -h0.y, h1.x, -h1.y};
     } else {
       const cf n0 = buf[tridx<T>(NC - k, tt)], n1 = buf[tridx<T>(NC - k, tt + 1)];
-      const cf w = tw_r2c[k];
+      if (zero_behind) {
+        buf[tridx<T>(NC - k, tt)] = zz;
+        buf[tridx<T>(NC - k, tt + 1)] = zz;
+      }
+      const cf w = wpre ? wpre[i] : tw_r2c[k];   // (wpre: the thread's ITEMS / NT twiddles, loaded once per kernel)
       const cf s0 = make_float2(a0.x + n0.x, a0.y - n0.y), d0 = make_float2(a0.x - n0.x, a0.y + n0.y);
       const cf s1 = make_float2(a1.x + n1.x, a1.y - n1.y), d1 = make_float2(a1.x - n1.x, a1.y + n1.y);
       const cf w0 = cmul(w, d0), w1 = cmul(w, d1);
@@ -957,12 +976,17 @@ __global__ void __launch_bounds__(TG* L, (NC == 1024 ? 4 : 1))
     const int a0 = (int)(tile % tiles) * T;
     const long long b = p.bg ? (long long)(bo / p.bg) * p.bg_in + p.b_off + (long long)(bo % p.bg) * p.bg_step : bo;   // batch as the input sees it
     const long long ogap = p.bg ? (long long)(bo / p.bg) * p.bg_gap : 0;
+#if VPS_Y_EARLY_G1
+    load_line(v1, tile, fresh(tid), TG);
+#endif
     {
       const int tida = fresh(tid);
       fft_from_regs_l<NC, L, WSYNC>(v0, buf + (tida / L) * PI::PITCH, tw, tida % L);
     }
     // (requesting the second group ahead of the first transform: 14.1 against 12.4 ms per 2048^3 launch)
+#if !VPS_Y_EARLY_G1
     load_line(v1, tile, fresh(tid), TG);
+#endif
     __syncthreads();  // every lane done with the per-line buffers
     {
       const int tidb = fresh(tid);
@@ -1095,6 +1119,13 @@ constexpr int pencil_lanes() {
 // 1024-point lines on the plan's 64 lanes (the 2048^3 grid): the twiddles of both later stages depend on the lane alone and
 // CAN stay in registers for the whole kernel (7 + 7 values; the second butterfly of stage 2 by constant 16th-root rotations:
 // 28 of the 32 LDS reads per lane and transform that are not data) -- measured slower here, unlike in the x pass, see below.
+#ifndef VPS_PENCIL_R2C_PRELOAD
+#define VPS_PENCIL_R2C_PRELOAD 0
+#endif
+#ifndef VPS_PENCIL_ZERO_BEHIND
+#define VPS_PENCIL_ZERO_BEHIND 0   // the epilogue of a component clears the image behind itself: no dense zero-fill for the next one
+                                   // (measured at C4: vector launch 28.3 against 27.2 ms -- the epilogue is where the kernel is slowest)
+#endif
 #ifndef VPS_PENCIL_PERSIST
 #define VPS_PENCIL_PERSIST 0   // 1: persistent workgroups with the next pencil's records prefetched (see the kernel).  Measured at C4,
                                // twice (rounds 2 and 4, the second time with the bounds, cells and first values of the next pencil
@@ -1163,6 +1194,16 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
   unsigned s_n = 0, e_n = 0, pencil_n = 0;
   if constexpr (TWL)
     for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
+  // the real-to-complex twiddles of this thread's rows in the 16-byte epilogue: k = tid / (TP / 2) + i NT / (TP / 2), the same
+  // for every component (and pencil) -- loaded once instead of one dependent global load per component ahead of the stores
+  constexpr int WHO0 = ENERGY ? 2 : 1;
+  constexpr bool ST16_0 = (VPS_ST16_MODE & WHO0) && TP >= 8 && TP <= 16 && (VPS_ST16_ALL || TP == 8) && (NC & 1) == 0 && ((NC / 2) * (TP / 2)) % NT == 0;
+  constexpr int NW = (ST16_0 && VPS_PENCIL_R2C_PRELOAD) ? ((NC / 2) * (TP / 2)) / NT : 0;
+  cf wr2c[NW > 0 ? NW : 1];
+  if constexpr (NW > 0) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) wr2c[i] = p.tw_r2c[(tid + i * NT) / (TP / 2)];
+  }
   cf twr1[(TWR & 1) ? (PI::R1 - 1) : 1], twr2[(TWR & 2) ? (PI::R2 - 1) : 1];
   if constexpr ((TWR & 1) != 0) load_stage_twiddles<NC, L, RL, PI::R1, PI::NS1>(twr1, p.tw_stage, l);
   if constexpr ((TWR & 2) != 0) load_stage_twiddles<NC, L, RL, PI::R2, PI::NS2>(twr2, p.tw_stage + PI::TW1, l);
@@ -1260,7 +1301,13 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
     // 4-byte writes) instead of a dense fill of the whole region (64 - 128 KB at the LDS write rate: 830 - 1500 clk per round).
     // After a transform the region is FFT scratch and needs the dense fill.
     const bool sparse_clear = ENERGY ? (c > 0) : (divide && c == 0);
-    if (sparse_clear) {
+    // ZB: the previous component's epilogue left the region all zero behind itself (r2c_store_tile16: zero_behind)
+    constexpr int WHO_ = ENERGY ? 2 : 1;
+    constexpr bool ZB = VPS_PENCIL_ZERO_BEHIND && !ENERGY && (VPS_ST16_MODE & WHO_) && TP == 8 && (NC & 1) == 0 &&
+                        ((NC / 2) * (TP / 2)) % NT == 0 && ACC * 4 <= NC * TP * 8;
+    const bool prezeroed = ZB && c > 0;
+    if (prezeroed) {
+    } else if (sparse_clear) {
 #pragma unroll
       for (int k = 0; k < KR; ++k)
         if (rloc[k] != 0xffffffffu) acc[rloc[k]] = 0.f;
@@ -1270,7 +1317,7 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
       for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
 #endif
     }
-    __syncthreads();
+    if (!prezeroed) __syncthreads();
     const bool rho_round = ENERGY && c == p.ncomp;
     const int word = rho_round ? 4 : 1 + p.chan[c < p.ncomp ? c : 0];
     // velocity: each term is divided by its cell's rho as it is added -- sum_k (q_k / rho) for the reference's
@@ -1369,7 +1416,7 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
     constexpr bool ST16 = (VPS_ST16_MODE & WHO) && TP >= 8 && TP <= 16 && (VPS_ST16_ALL || TP == 8) && (NC & 1) == 0 && ((NC / 2) * (TP / 2)) % NT == 0;
     constexpr bool PLAIN = (VPS_PLAIN_MODE & WHO) && TP < 16;
     if constexpr (ST16)
-      r2c_store_tile16<NC, TP, NT, PLAIN>(buf, tidc, p.tw_r2c, out, N, nyq);
+      r2c_store_tile16<NC, TP, NT, PLAIN>(buf, tidc, p.tw_r2c, out, N, nyq, ZB && c + 1 < nround, NW > 0 ? wr2c : nullptr);
     else
       r2c_store_tile<NC, TP, NT, false, PLAIN>(buf, tidc, p.tw_r2c, out, N, nyq, TP);
   }
@@ -1494,11 +1541,12 @@ struct XParams {
 // With integer shells the 2048-point plan also keeps its last stage's twiddles in registers (x_twreg): thresholds 4 KB + sums
 // 8 KB + counts 4 KB + stage-1 twiddles 2 KB + two lines 34 KB = 52 KB, so THREE workgroups share a CU instead of two
 // (70.6 KB before).  Measured at C4: persistent workgroups per CU 1 -> 2: 35.7 -> 22.7 ms per vector launch.
-// (Lines made of segments -- the received blocks of a slab exchange -- keep the twiddles in LDS: with the segment arithmetic
-//  next to 14 twiddle registers the kernel does not fit the 168 VGPRs of three waves per SIMD: 97 registers spilled.)
+// (Lines made of segments -- the received blocks of a slab exchange -- take the same form: their loads are a scalar base and
+//  one lane offset, load_line.  While the kernel also carried the general segment addressing, a 64-bit offset per element for
+//  segments shorter than a line's lanes, that path alone cost 60 VGPRs and the register-twiddle variant spilled 97.)
 template <int NC, int FASTMODE, bool SEG>
 constexpr bool x_twreg() {
-  return FASTMODE == 2 && !SEG && NC == 2048 && PlanInfo<NC>::R2 > 1;
+  return FASTMODE == 2 && NC == 2048 && PlanInfo<NC>::R2 > 1;
 }
 template <int NC, int T, int MODE, bool SEG, bool COUNT, int FASTMODE>
 #ifndef VPS_X_MIN_WAVES
@@ -1670,7 +1718,10 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, (x_twreg<NC, FASTMODE, SEG
       // elements, element x = l + xr (xr = L m + r NC/R, a multiple of L) sits in segment xr >> seg_shift at offset
       // (xr & segmask) + l with no carry.  Everything but l is then scalar: the loads take an SGPR base and one 32-bit lane
       // offset instead of a 64-bit multiply-add per element (x pass of a received 2048^3 chunk, 8 segments: 4.22 -> see DESIGN).
-      if (p.seg_shift >= 0 && p.seglen >= L) {
+      // (power-of-two lines: launch_x refuses segments shorter than L -- more than NC / L ranks -- so this is the only path the
+      //  kernel carries for them; the general form below, with a 64-bit offset per element, costs it ~60 VGPRs)
+      constexpr bool ONLY_SCALAR = (NC & (NC - 1)) == 0;
+      if (ONLY_SCALAR || (p.seg_shift >= 0 && p.seglen >= L)) {
         const unsigned long long ub = reinterpret_cast<unsigned long long>(base);
         const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)ub), bhi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
         const cf* sbase = reinterpret_cast<const cf*>(((unsigned long long)bhi << 32) | blo);
@@ -1680,18 +1731,23 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, (x_twreg<NC, FASTMODE, SEG
         int sh = p.seg_shift;
         asm volatile("" : "+s"(sh));
         const int smask = (1 << sh) - 1;
+        if (__builtin_amdgcn_readfirstlane((int)live)) {   // (wave-uniform: one scalar branch around all the loads)
 #pragma unroll
-        for (int m = 0; m < NB; ++m)
+          for (int m = 0; m < NB; ++m)
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int xr = L * m + r * (NC / R);
-            const long long off = (long long)(xr >> sh) * p.seg_stride + (xr & smask);
-            // (uniform 64-bit base + zero-extended 32-bit lane offset: the saddr + voffset form of global_load, one VGPR of
-            //  address for all loads instead of a 64-bit VGPR pair each)
-            const char* sb = reinterpret_cast<const char*>(sbase + off);
-            const double raw = live ? __builtin_nontemporal_load(reinterpret_cast<const double*>(sb + (unsigned)l * 8u)) : 0.0;
-            v[m * R + r] = *reinterpret_cast<const cf*>(&raw);
-          }
+            for (int r = 0; r < R; ++r) {
+              const int xr = L * m + r * (NC / R);
+              const long long off = (long long)(xr >> sh) * p.seg_stride + (xr & smask);
+              // (uniform 64-bit base + zero-extended 32-bit lane offset: the saddr + voffset form of global_load, one VGPR of
+              //  address for all loads instead of a 64-bit VGPR pair each)
+              const char* sb = reinterpret_cast<const char*>(sbase + off);
+              const double raw = __builtin_nontemporal_load(reinterpret_cast<const double*>(sb + (unsigned)l * 8u));
+              v[m * R + r] = *reinterpret_cast<const cf*>(&raw);
+            }
+        } else {
+#pragma unroll
+          for (int i = 0; i < RL; ++i) v[i] = make_float2(0.f, 0.f);
+        }
         return;
       }
     }
@@ -2111,12 +2167,14 @@ int launch_x(vps_ctx* ctx, const XParams& p_in, int fast = 0) {   // fast: 0 gen
   typedef PlanInfo<NC> PI;
   if (!(MODE == 0 && NC >= 32)) fast = 0;
   const bool seg = p.seglen != NC;
-  const bool twreg = fast == 2 && !seg && x_twreg<NC, 2, false>();
+  const bool twreg = fast == 2 && x_twreg<NC, 2, false>();
   size_t lds = ((twreg ? ((PI::TW1 + 1) & ~1) : PI::TWL) + (size_t)T * PI::PITCH) * sizeof(cf);
   if (MODE == 0) lds += (fast == 2 ? (size_t)((p.nbins + 3) & ~1) * sizeof(unsigned) : (size_t)(p.nbins + 2) * sizeof(double)) +
                         (size_t)p.nbins * sizeof(double) + (COUNT ? (size_t)p.nbins * sizeof(unsigned) : 0) +
                         (p.win ? (size_t)NC * sizeof(float) : 0);
   if (lds > ctx->lds_per_cu) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "x pass needs %zu B LDS", lds);
+  if (seg && (NC & (NC - 1)) == 0 && PI::L % 64 == 0 && (p.seg_shift < 0 || p.seglen < PI::L))
+    return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "x pass: lines of %d points in segments of %d (more than %d ranks)", NC, p.seglen, NC / PI::L);
   auto kern = seg ? fft_x_pass<NC, T, MODE, true, COUNT, 0> : fft_x_pass<NC, T, MODE, false, COUNT, 0>;
   if constexpr (MODE == 0 && NC >= 32) {
     if (fast == 1) kern = seg ? fft_x_pass<NC, T, MODE, true, COUNT, 1> : fft_x_pass<NC, T, MODE, false, COUNT, 1>;
