@@ -71,7 +71,12 @@ int vps_version(void);                            /* ABI version (VPS_ABI_VERSIO
  * change a code path; the host sets what it wants explicitly (vpower/_ffi.py maps VPS_OPT_<NAME> variables once, at load,
  * and lists them in _ffi.OPTIONS).  Names: no_fast_binning, no_pair_binning, nn_query_centric, nn_column, nn_build_atomic, nn_kappa, nn_stats,
  * sort_groups, sort_staged, sort_atomic (all result-preserving), nn_ablate (timing-only builds; ignored by the product
- * build).  A NaN value restores the default.  Unknown names: VPS_ERR_ARG. */
+ * build).  A NaN value restores the default.  Unknown names: VPS_ERR_ARG.
+ * Further names: no_int_binning (1: float64 shells even where integer shells are exact), x_wg_per_cu (persistent x-pass workgroups
+ * per CU, tuning), comm_fail_send (error-path tests: the n-th ncclSend fails without being issued).
+ * Options that shape a WORKSPACE LAYOUT -- nn_build_atomic, sort_atomic, sort_staged, sort_groups -- must not change between a
+ * *_workspace_bytes call and the run that uses the workspace sized with it (nor before a VPS_FLAG_REUSE_SORT call): the run
+ * entry points take no size and recompute the layout under the current values. */
 int vps_set_option(const char* name, double value);
 double vps_get_option(const char* name, double dflt);
 /* device facts for the host side: out[0]=CUs, out[1]=LDS bytes/CU, out[2]=wave size,

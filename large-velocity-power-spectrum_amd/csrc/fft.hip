@@ -1105,14 +1105,15 @@ constexpr int pencil_lanes() {
 
 // Epilogue of 8-line pencils (2048- and 4096-cell lines; measured at C4, ms per launch, vector / energy): 8-byte streaming
 // stores 29.5 / 11.5 (rounds 2-3); 8-byte plain 30.6 / 10.95; 16-byte streaming 27.4 / 12.4; 16-byte plain 27.0 / 10.2 -- the
-// epilogue is bound by store ISSUE (half the instructions with dwordx4), and half lines merge in L2 with the partner pencil's
-// only when they are not marked streaming (PMC: energy launch 44.9 -> 35.1 GB written for 34.4 GB of output).
+// epilogue is bound by store ISSUE (half the instructions with dwordx4); the energy launch, whose workgroups live for one
+// component only, merges its half lines in L2 with the partner pencil's when they are not marked streaming (PMC: 44.9 -> 35.1 GB
+// written for 34.4 GB of output).
 #ifndef VPS_ST16_MODE
 #define VPS_ST16_MODE 3   // bit 0: vector launches, bit 1: the energy launch
 #endif
 #ifndef VPS_PLAIN_MODE
-#define VPS_PLAIN_MODE 3   // (vector launches: plain and streaming 16-byte stores time alike -- 27.0 against 26.95 ms -- but the half
-#endif                     //  lines of two partner pencils merge in L2 only when unmarked: PMC 117 GB written for 103 GB with streaming stores)
+#define VPS_PLAIN_MODE 2   // (vector launches with plain 16-byte stores: 27.0 ms on one box, 30.7 on two others, against 26.5 - 27.6 with
+#endif                     //  streaming stores everywhere; PMC 113.9 against 117.2 GB written for 103.2 GB of output: not worth the risk)
 #ifndef VPS_ST16_ALL
 #define VPS_ST16_ALL 0    // 1: 16-byte stores for 16-line pencils too (experiment)
 #endif

@@ -55,9 +55,10 @@ __global__ void __launch_bounds__(1024) scan_tile_offsets(unsigned* __restrict__
   }
 }
 
+// (count and start may be the SAME array -- the NN cell list scans its table in place: no __restrict__ on them; a thread loads
+//  its SCAN_ITEMS counts before it stores, and no thread stores into another thread's counts)
 __global__ void __launch_bounds__(SCAN_BLOCK)
-    scan_apply(const unsigned* __restrict__ count, long long n, const unsigned* __restrict__ tile_off,
-               unsigned* __restrict__ start) {
+    scan_apply(const unsigned* count, long long n, const unsigned* __restrict__ tile_off, unsigned* start) {
   // each thread owns SCAN_ITEMS consecutive counts
   __shared__ unsigned sh[SCAN_BLOCK];
   const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;

@@ -337,8 +337,11 @@ class HipKernels:
         token holds WEAK references to the tensors (a freed tensor whose address is recycled cannot pass for the old
         one, and nothing is kept alive by the library) and their in-place modification counters; any mismatch silently
         sorts again.  Records the token of THIS call."""
+        # (the library options that decide the record layout are part of the state: a sort made under one value of
+        #  sort_atomic / sort_staged / sort_groups cannot be reused under another)
+        layout_opts = tuple(sorted((k, v) for k, v in _ffi.OPTIONS.items() if k.startswith("sort_")))
         state = (weakref.ref(pos), weakref.ref(vel), weakref.ref(rho), pos._version, vel._version, rho._version,
-                 int(N), float(Lbox), int(x0), int(nx), work.data_ptr(), cap)
+                 int(N), float(Lbox), int(x0), int(nx), work.data_ptr(), cap, layout_opts)
         last = getattr(self, "_fused_token", None)
         ok = (reuse_sort is not None and reuse_sort is last
               and all(r() is t for r, t in zip(last[:3], (pos, vel, rho))) and last[3:] == state[3:])
