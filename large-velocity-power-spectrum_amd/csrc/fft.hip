@@ -1217,7 +1217,11 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
   // inside a round (tail loops below); their per-record value lives in p.side[record].
   // register-resident record groups: enough for a typical bucket (~1.2 x mean occupancy at the bench
   // densities) -- 3 x 256 threads at 512^3, 2 x 512 at 1024^3 (measured optimum each)
+#ifdef VPS_PENCIL_KR
+  constexpr int KR = VPS_PENCIL_KR;
+#else
   constexpr int KR = NT >= 512 ? 2 : (NT >= 256 ? 3 : 4);
+#endif
   unsigned rloc[KR];
   float rval[KR];
   float rrec[KR];   // 1/rho of the record's cell (velocity) / sum over components of (rho v_c)^2 of its cell (ENERGY)
@@ -1256,7 +1260,11 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
   }
   const int x = pencil / p.nby, y0 = (pencil % p.nby) * TP;
   // more than two particles per cell on average: hot cells are likely, take the native atomics (vps_lds_add)
+#ifdef VPS_PENCIL_NATIVE_ADD
+  const bool crowded = true;
+#else
   const bool crowded = (e - s) > 2u * (unsigned)ACC;
+#endif
 #pragma unroll
   for (int k = 0; k < KR; ++k) rrec[k] = 1.f;
   const unsigned tail0 = s + tid + KR * NT;   // this thread's first record beyond the register-resident ones
@@ -1292,7 +1300,9 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
     // opaque copies: keeps the compiler from hoisting ~50 loop-invariant LDS addresses out of the
     // component loop (they cost more registers than they save instructions, and an occupancy step)
     int lc = l, tc = t, tidc = tid;
+#ifndef VPS_PENCIL_NO_OPAQUE
     asm volatile("" : "+v"(lc), "+v"(tc), "+v"(tidc));
+#endif
     lc &= L - 1;   // give the value ranges back to the compiler (address folding needs them)
     tc &= TP - 1;
     tidc &= NT - 1;
@@ -1831,7 +1841,9 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, (x_twreg<NC, FASTMODE, SEG
         // opaque copy of the lane index: keeps the LDS / global addresses of this loop from being
         // hoisted out of it as ~50 extra live registers (an occupancy step)
         int lc = l;
+#ifndef VPS_X_NO_OPAQUE
         asm volatile("" : "+v"(lc));
+#endif
         lc = (L & (L - 1)) == 0 ? (lc & (L - 1)) : lc % L;   // give the value range back to the compiler (address folding needs it)
 #ifdef VPS_X_PREFETCH
         // second register set: the NEXT line set (next component of this tile, or the first of the next tile) is requested
@@ -1871,7 +1883,9 @@ __global__ void __launch_bounds__(T* PlanInfo<NC>::L, (x_twreg<NC, FASTMODE, SEG
       constexpr int CH = FAST ? H : RL;              // chunk length; one pad word per chunk
       {
         int lw = l;   // opaque again: 16 store addresses recomputed per tile instead of kept live
+#ifndef VPS_X_NO_OPAQUE
         asm volatile("" : "+v"(lw));
+#endif
         lw = (L & (L - 1)) == 0 ? (lw & (L - 1)) : lw % L;
 #pragma unroll
         for (int i = 0; i < RL; ++i) {
