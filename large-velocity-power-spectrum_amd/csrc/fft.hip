@@ -1445,6 +1445,305 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
  }
 }
 
+// ------------------------------------------------------------------------------
+// Split pencil: the same pencil (TP = 8 y-lines) on HALF the threads -- a workgroup runs the deposit rounds and the transform of
+// lines 0..3, parks their spectrum in registers (RL values per lane), does the same for lines 4..7, and only then stages the
+// transposed image of all eight lines and stores it.  The LDS region is that of FOUR lines: at 4096-cell lines 67.6 KB instead
+// of 135 KB (+ 16 KB of twiddles, now read through L2 as the 4096-point y pass does), so TWO workgroups of 512 threads share a
+// CU where one of 1024 ran alone with every phase exposed (pencil kernel at 0.26 of peak at N = 4096).
+// The image of eight lines no longer fits either: it is staged in two halves of the mode PAIRS -- the real-to-complex step needs
+// Z[k] with Z[NC - k]: after the last radix-R stage register slot (m, r) holds k = l + L m + r NC/R, so r < R/4 and
+// r >= 3R/4 are exactly the modes k < NC/4 and k >= 3 NC/4 (the pairs of the first half), the middle slots the second.
+// Every record is looked at once per half (a record belongs to the half that holds its line); everything else -- per-record
+// 1/rho and energy sums, sparse clears, CAS-first LDS adds, the 16-byte epilogue -- is the pencil kernel's.
+// ------------------------------------------------------------------------------
+template <int NC, int TP, bool ENERGY>
+__global__ void __launch_bounds__((TP / 2) * pencil_lanes<NC>(), 4) pencil_split_fft_z_kernel(const PencilParams p) {
+  typedef PlanInfo<NC> PI;
+  constexpr int L = pencil_lanes<NC>(), RL = NC / L, TH = TP / 2, NT = TH * L, N = 2 * NC;
+  constexpr int R = LastRadix<NC>::R;
+  static_assert(TP == 8 && (R % 4) == 0 && (NC % 4) == 0, "eight lines in two halves, image in two halves of the mode pairs");
+  constexpr int ACC = TH * N;                       // floats of one accumulator (four lines)
+  constexpr int LINES = TH * PI::PITCH * 2;         // floats of the exchange buffers
+  constexpr int IMG = (NC / 2) * TP * 2;            // floats of half an image: NC/2 modes x 8 lines
+  constexpr int SHARED = (ACC > LINES ? (ACC > IMG ? ACC : IMG) : (LINES > IMG ? LINES : IMG));
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* acc = reinterpret_cast<float*>(smem_raw);
+  cf* buf = reinterpret_cast<cf*>(acc);
+  // Z[3 NC/4] of the eight lines: its partner Z[NC/4] sits in the OTHER half image (slot r = R/4 against r = 3R/4), so the first
+  // image phase leaves it here for the second
+  cf* edge = reinterpret_cast<cf*>(acc + SHARED);
+  const cf* tw = p.tw_stage;                        // (through L2: the region is the whole of the workgroup's LDS)
+
+  const int tid = threadIdx.x;
+  const int t = tid / L, l = tid % L;
+  unsigned pencil = blockIdx.x;
+  {   // the two pencils that complete a 128-byte output line on ONE XCD, close in time (as in pencil_fft_z_kernel)
+    constexpr unsigned GP = 16 / TP, span = 8 * GP;
+    if (pencil / span < p.npencils / span) {
+      const unsigned base = (pencil / span) * span, h = pencil % span;
+      pencil = base + GP * (h % 8) + (h / 8);
+    }
+  }
+  const int x = pencil / p.nby, y0 = (pencil % p.nby) * TP;
+  const unsigned s = p.start[pencil], e = p.start[pencil + 1];
+  const bool crowded = (e - s) > 4u * (unsigned)ACC;
+  constexpr int KR = 2;      // register-resident record groups: 2 x 256 / 2 x 512 threads hold a typical bucket of EIGHT lines
+  constexpr int NW_ = ENERGY ? 4 : 3;
+  unsigned rloc[KR];         // cell inside the pencil: line * N + z
+  float rw[KR][NW_];         // the record's values [rho v_x, rho v_y, rho v_z (, rho)]: every round of both halves reads them here
+  float rrec[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const unsigned j = s + tid + k * NT;
+    rloc[k] = 0xffffffffu;
+    rrec[k] = 1.f;
+    if (j < e) {
+      const unsigned* rec = p.records + (size_t)j * 5;
+      rloc[k] = rec[0];
+#pragma unroll
+      for (int w_ = 0; w_ < NW_; ++w_) rw[k][w_] = __uint_as_float(rec[1 + w_]);
+    }
+  }
+  const bool divide = !ENERGY && p.divide;
+  const unsigned tail0 = s + tid + KR * NT;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int R0 = PI::R0, NB0 = RL / R0;
+  constexpr bool WSYNC = (L <= 64) && (64 % L == 0);
+  // cell of a record inside the half that is being worked on, or 0xffffffff: not this half's
+  auto local = [&](unsigned cell, int h) -> unsigned {
+    const unsigned lo = (unsigned)h * (unsigned)ACC;
+    return (cell - lo) < (unsigned)ACC ? cell - lo : 0xffffffffu;     // (0xffffffff - lo wraps far beyond ACC)
+  };
+  auto dense_clear = [&]() {
+    for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
+  };
+  // one accumulation round of half h: adds `word` of every record of the half (times its 1/rho when dividing)
+  auto scatter = [&](int h, int word, bool times_rrec) {
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const unsigned c_ = local(rloc[k], h);
+      if (c_ != 0xffffffffu) {
+        float v_;
+        if constexpr (ENERGY) {
+          v_ = word == 1 ? rw[k][0] : (word == 2 ? rw[k][1] : (word == 3 ? rw[k][2] : rw[k][NW_ - 1]));
+        } else {   // (vector launches keep three words; rho -- the dividing launches' first rounds -- is read where it is used)
+          v_ = word == 1 ? rw[k][0] : (word == 2 ? rw[k][1] : (word == 3 ? rw[k][2]
+                                                                          : __uint_as_float(p.records[(size_t)(s + tid + k * NT) * 5 + 4])));
+        }
+        vps_lds_add(&acc[c_], times_rrec ? v_ * rrec[k] : v_, crowded);
+      }
+    }
+    for (unsigned j = tail0; j < e; j += NT) {
+      const unsigned* rec = p.records + (size_t)j * 5;
+      const unsigned c_ = local(rec[0], h);
+      if (c_ != 0xffffffffu) {
+        const float v_ = __uint_as_float(rec[word]);
+        vps_lds_add(&acc[c_], times_rrec ? v_ * p.side[j] : v_, crowded);
+      }
+    }
+  };
+  auto sparse_clear = [&](int h) {
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const unsigned c_ = local(rloc[k], h);
+      if (c_ != 0xffffffffu) acc[c_] = 0.f;
+    }
+    for (unsigned j = tail0; j < e; j += NT) {
+      const unsigned c_ = local(p.records[(size_t)j * 5], h);
+      if (c_ != 0xffffffffu) acc[c_] = 0.f;
+    }
+  };
+
+  // ---- velocity: 1 / rho of every record's cell, half by half ----
+  if (divide) {
+    for (int h = 0; h < 2; ++h) {
+      __syncthreads();
+      dense_clear();
+      __syncthreads();
+      scatter(h, 4, false);
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < KR; ++k) {
+        const unsigned c_ = local(rloc[k], h);
+        if (c_ != 0xffffffffu) {
+          const float r = acc[c_];
+          rrec[k] = r != 0.f ? __builtin_amdgcn_rcpf(r) : 0.f;
+        }
+      }
+      for (unsigned j = tail0; j < e; j += NT) {
+        const unsigned c_ = local(p.records[(size_t)j * 5], h);
+        if (c_ != 0xffffffffu) {
+          const float r = acc[c_];
+          p.side[j] = r != 0.f ? __builtin_amdgcn_rcpf(r) : 0.f;
+        }
+      }
+    }
+  }
+  // ---- ENERGY: per record the sum over components of (cell total of rho v_c)^2, half by half and component by component ----
+  if constexpr (ENERGY) {
+    for (int h = 0; h < 2; ++h)
+      for (int c = 0; c < p.ncomp; ++c) {
+        __syncthreads();
+        if (c == 0) dense_clear(); else sparse_clear(h);
+        __syncthreads();
+        scatter(h, 1 + p.chan[c], false);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+          const unsigned c_ = local(rloc[k], h);
+          if (c_ != 0xffffffffu) {
+            const float q = acc[c_];
+            rrec[k] = (c == 0) ? q * q : rrec[k] + q * q;
+          }
+        }
+        for (unsigned j = tail0; j < e; j += NT) {
+          const unsigned c_ = local(p.records[(size_t)j * 5], h);
+          if (c_ != 0xffffffffu) {
+            const float q = acc[c_];
+            p.side[j] = (c == 0) ? q * q : p.side[j] + q * q;
+          }
+        }
+      }
+  }
+
+  // ---- per output field: both halves accumulated and transformed, then the image of all eight lines in two halves ----
+  const int nfields = ENERGY ? 1 : p.ncomp;
+  for (int c = 0; c < nfields; ++c) {
+    cf vpark[RL], v[RL];
+    for (int h = 0; h < 2; ++h) {
+      int lc = l, tc = t;
+      asm volatile("" : "+v"(lc), "+v"(tc));   // (keeps the LDS addresses of the two halves from being formed up front)
+      lc &= L - 1;
+      tc &= TH - 1;
+      __syncthreads();   // previous image / previous half's exchange buffers consumed
+      dense_clear();
+      __syncthreads();
+      if constexpr (ENERGY) {
+        scatter(h, 4, false);              // rho
+        __syncthreads();
+        // E = vol * sum / rho where there is mass: every record writes its cell's value once all have read rho
+        float ev[KR];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+          const unsigned c_ = local(rloc[k], h);
+          ev[k] = 0.f;
+          if (c_ != 0xffffffffu) {
+            const float r = acc[c_];
+            ev[k] = r != 0.f ? rrec[k] * __builtin_amdgcn_rcpf(r) * p.vol : 0.f;
+          }
+        }
+        for (unsigned j = tail0; j < e; j += NT) {
+          const unsigned c_ = local(p.records[(size_t)j * 5], h);
+          if (c_ != 0xffffffffu) {
+            const float r = acc[c_];
+            p.side[j] = r != 0.f ? p.side[j] * __builtin_amdgcn_rcpf(r) * p.vol : 0.f;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+          const unsigned c_ = local(rloc[k], h);
+          if (c_ != 0xffffffffu) acc[c_] = ev[k];
+        }
+        for (unsigned j = tail0; j < e; j += NT) {
+          const unsigned c_ = local(p.records[(size_t)j * 5], h);
+          if (c_ != 0xffffffffu) acc[c_] = p.side[j];
+        }
+      } else {
+        scatter(h, 1 + p.chan[c], divide);
+      }
+      __syncthreads();
+      {
+        const float* q = acc + tc * N;
+        const float sc = (ENERGY || divide) ? 1.f : p.vol;
+#pragma unroll
+        for (int m = 0; m < NB0; ++m)
+#pragma unroll
+          for (int rr = 0; rr < R0; ++rr) {
+            const int j = lc + L * m + rr * (NC / R0);
+            const float2 qq = *reinterpret_cast<const float2*>(q + 2 * j);
+            v[m * R0 + rr] = make_float2(qq.x * sc, qq.y * sc);
+          }
+      }
+      __syncthreads();   // accumulator consumed: its memory becomes FFT scratch
+      fft_from_regs_l<NC, L, WSYNC>(v, buf + tc * PI::PITCH, tw, lc);
+      if (h == 0) {
+#pragma unroll
+        for (int i = 0; i < RL; ++i) vpark[i] = v[i];
+      }
+    }
+    // ---- image halves: pairs (k, NC - k) with min(k, NC - k) < NC/4 first, the rest second ----
+    cf* out = p.out[c] + (long long)x * NC * N + y0;
+    cf* nyq = p.nyq[c] + (long long)x * N + y0;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      int lc = l, tc = t, tidc = tid;
+      asm volatile("" : "+v"(lc), "+v"(tc), "+v"(tidc));
+      lc &= L - 1;
+      tc &= TH - 1;
+      tidc &= NT - 1;
+      __syncthreads();   // exchange buffers / the previous half image are free
+      // row kk of the half image: k < NC/4 -> kk = k; k >= 3NC/4 -> kk = k - NC/2  (g = 0);  NC/4 <= k < 3NC/4 -> kk = k - NC/4 (g = 1)
+#pragma unroll
+      for (int i = 0; i < RL; ++i) {
+        const int r = i % R;
+        const bool outer = (r < R / 4) || (r >= 3 * R / 4);
+        if (outer == (g == 0)) {
+          const int k = out_index_l<NC, L>(lc, i);
+          const int kk = (g == 0) ? ((r < R / 4) ? k : k - NC / 2) : k - NC / 4;
+          buf[tridx<TP>(kk, tc)] = vpark[i];
+          buf[tridx<TP>(kk, tc + TH)] = v[i];
+          if (g == 0 && i == 3 * R / 4 && lc == 0) {   // slot (m = 0, r = 3R/4) of lane 0: mode 3 NC/4
+            edge[tc] = vpark[i];
+            edge[tc + TH] = v[i];
+          }
+        }
+      }
+      __syncthreads();
+      // pairs of this half: k = 0 .. NC/4 - 1 with NC - k (g = 0; k = 0: the self-paired modes 0 and NC/2 -- NC/2 sits in
+      // the OTHER half image, so g = 0 writes X[0] and the Nyquist plane, g = 1 writes X[NC/2] from its own row);
+      // k = NC/4 .. NC/2 - 1 with NC - k, and the self-paired NC/2 (g = 1)
+      constexpr int H2 = TP / 2, ITEMS = (NC / 4) * H2;
+      static_assert(ITEMS % NT == 0, "whole rounds");
+#pragma unroll 4
+      for (int i = 0; i < ITEMS / NT; ++i) {
+        const int idx = tidc + i * NT;
+        const int tt = (idx % H2) * 2, kq = idx / H2;           // kq = 0 .. NC/4 - 1
+        const int k = (g == 0) ? kq : kq + NC / 4;              // the smaller mode of the pair
+        const int rowk = (g == 0) ? k : k - NC / 4;             // its row in this half image
+        const int rown = (g == 0) ? (NC - k) - NC / 2 : (NC - k) - NC / 4;   // row of NC - k (k > 0)
+        const cf a0 = buf[tridx<TP>(rowk, tt)], a1 = buf[tridx<TP>(rowk, tt + 1)];
+        if (g == 0 && k == 0) {
+          *reinterpret_cast<vps_f4*>(&out[tt]) = vps_f4{a0.x + a0.y, 0.f, a1.x + a1.y, 0.f};
+          *reinterpret_cast<vps_f4*>(&nyq[tt]) = vps_f4{a0.x - a0.y, 0.f, a1.x - a1.y, 0.f};
+        } else {
+          if (g == 1 && k == NC / 4) {
+            // (row NC/2 - NC/4 of this half image holds mode NC/2, which pairs with itself)
+            const cf h0 = buf[tridx<TP>(NC / 2 - NC / 4, tt)], h1 = buf[tridx<TP>(NC / 2 - NC / 4, tt + 1)];
+            *reinterpret_cast<vps_f4*>(&out[(long long)(NC / 2) * N + tt]) = vps_f4{h0.x, -h0.y, h1.x, -h1.y};
+          }
+          const bool at_edge = (g == 1 && k == NC / 4);      // partner 3 NC/4 was left in `edge` by the first phase
+          const cf n0 = at_edge ? edge[tt] : buf[tridx<TP>(rown, tt)], n1 = at_edge ? edge[tt + 1] : buf[tridx<TP>(rown, tt + 1)];
+          const cf w = p.tw_r2c[k];
+          const cf s0 = make_float2(a0.x + n0.x, a0.y - n0.y), d0 = make_float2(a0.x - n0.x, a0.y + n0.y);
+          const cf s1 = make_float2(a1.x + n1.x, a1.y - n1.y), d1 = make_float2(a1.x - n1.x, a1.y + n1.y);
+          const cf w0 = cmul(w, d0), w1 = cmul(w, d1);
+          const vps_f4 lo = {0.5f * (s0.x + w0.y), 0.5f * (s0.y - w0.x), 0.5f * (s1.x + w1.y), 0.5f * (s1.y - w1.x)};
+          const vps_f4 hi = {0.5f * (s0.x - w0.y), 0.5f * (-s0.y - w0.x), 0.5f * (s1.x - w1.y), 0.5f * (-s1.y - w1.x)};
+          if constexpr (ENERGY) {
+            *reinterpret_cast<vps_f4*>(&out[(long long)k * N + tt]) = lo;
+            *reinterpret_cast<vps_f4*>(&out[(long long)(NC - k) * N + tt]) = hi;
+          } else {
+            __builtin_nontemporal_store(lo, reinterpret_cast<vps_f4*>(&out[(long long)k * N + tt]));
+            __builtin_nontemporal_store(hi, reinterpret_cast<vps_f4*>(&out[(long long)(NC - k) * N + tt]));
+          }
+        }
+      }
+    }
+  }
+}
+
 // (A wave-private form -- every wave scans all records of the pencil, keeps those of its own line(s) and runs zero-fill, LDS
 // adds, read-back, stage-0 loads and the exchanges inside its own LDS region with wave-level ordering only, three workgroup
 // barriers per component instead of seven -- measured at C4: 97 against 75 ms per step of pencil launches, bit-identical
@@ -1475,9 +1774,44 @@ size_t pencil_lds_bytes() {
   return (size_t)(ACC > LINES ? ACC : LINES) * sizeof(float) + (size_t)(pencil_twreg<NC>() == 3 ? 0 : PI::TWL) * sizeof(cf);
 }
 
+// which line lengths run the split form (pencil_split_fft_z_kernel): bit 0 -- 1024 packed points (2048-cell lines), bit 1 -- 2048
+// (4096-cell lines, where the whole pencil leaves one workgroup per CU)
+#ifndef VPS_PENCIL_SPLIT
+#define VPS_PENCIL_SPLIT 2
+#endif
+template <int NC>
+constexpr bool pencil_split() {
+  return pencil_tp<NC>() == 8 && (LastRadix<NC>::R % 4) == 0 &&
+         ((NC == 1024 && (VPS_PENCIL_SPLIT & 1)) || (NC == 2048 && (VPS_PENCIL_SPLIT & 2)));
+}
+template <int NC>
+size_t pencil_split_lds_bytes() {
+  typedef PlanInfo<NC> PI;
+  constexpr int TH = pencil_tp<NC>() / 2;
+  constexpr size_t ACC = (size_t)TH * 2 * NC, LINES = (size_t)TH * PI::PITCH * 2, IMG = (size_t)(NC / 2) * pencil_tp<NC>() * 2;
+  const size_t shared = ACC > LINES ? (ACC > IMG ? ACC : IMG) : (LINES > IMG ? LINES : IMG);
+  return shared * sizeof(float) + (size_t)pencil_tp<NC>() * sizeof(cf);
+}
+
 template <int NC>
 int launch_pencil(vps_ctx* ctx, const PencilParams& p, long long npencils) {
   typedef PlanInfo<NC> PI;
+  if constexpr (pencil_split<NC>()) if (p.energy) {   // (the vector form of the split kernel does not fit 128 VGPRs: whole pencils there)
+    const size_t lds2 = pencil_split_lds_bytes<NC>();
+    constexpr int TP2 = pencil_tp<NC>();
+    auto kern2 = pencil_split_fft_z_kernel<NC, TP2, true>;
+    if (lds2 > 64 * 1024)
+      VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern2),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    PencilParams pp2 = p;
+    pp2.npencils = (unsigned)npencils;
+    {
+      vps_launch_timer tm(ctx, VPS_K_FFT_Z);
+      hipLaunchKernelGGL(kern2, dim3((unsigned)npencils), dim3((TP2 / 2) * pencil_lanes<NC>()), lds2, ctx->stream, pp2);
+    }
+    VPS_HIP_CHECK(ctx, hipGetLastError());
+    return VPS_OK;
+  }
   const size_t lds = pencil_lds_bytes<NC>();
   constexpr int PENCIL_TP = pencil_tp<NC>();
   if (lds > ctx->lds_per_cu) return vps_fail(ctx, VPS_ERR_UNSUPPORTED, "pencil kernel needs %zu B LDS", lds);
