@@ -23,6 +23,8 @@
 #include <cmath>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "vps_internal.h"
 #include "scan.h"
 
@@ -1076,8 +1078,9 @@ constexpr int NC_TX = 16, NC_TY = 16, NC_TZ = 32;
 constexpr int NC_THREADS = 256;
 constexpr int NC_WIN = 8;                       // z-points a particle is evaluated for
 constexpr int NC_NCLS = NC_TZ - NC_WIN + 1;     // window starts 0 .. 24
-constexpr int NC_SEG = 1280;                    // region particles staged in LDS at a time
+constexpr int NC_SEG = 1216;                    // region particles staged in LDS at a time (slot NC_SEG: the dummy record)
 constexpr int NC_MAXCOL = 1024;
+constexpr int NC_SMAX = NC_SEG / 4 - 2;         // steps of a wave's padded quadrant lists (two more are read ahead)
 
 // search radius of a tile from the particles in the cells c0..c1 that hold its lattice points
 __device__ __forceinline__ double nc_radius(const NnGrid& g, const int (&c0)[3], const int (&c1)[3], unsigned cnt, float kappa,
@@ -1142,68 +1145,115 @@ __device__ __forceinline__ unsigned nc_umed3(unsigned a, unsigned b, unsigned c)
   return r;
 }
 
-// all particles of window class Z0 in this wave's list: entries [beg, end) of ord
-template <int Z0>
-__device__ __forceinline__ void nc_run_class(unsigned (&k1)[NC_TZ], unsigned (&k2)[NC_TZ],
-                                             const float4* __restrict__ P, const unsigned short* __restrict__ ord,
-                                             unsigned beg, unsigned end, const float* __restrict__ qfz, float qxl, float qyl,
-                                             int lane) {
+// Window class Z0 of a wave's lists: steps [beg, end).  The wave's 8 x 8 patch is walked as four 4 x 4 QUADRANTS of 16 lanes,
+// each with its own list of the particles whose R-disc meets it (a disc covers 32 h^2 of the 207 h^2 footprint of the whole
+// patch + R, of a quadrant's 108 h^2: half the pair evaluations).  The window start still decides which registers are touched,
+// so the four lists advance class by class in lockstep: entry (step, quadrant) of `ordq` is a staged slot, or the dummy slot
+// whose record is NaN -- its keys lose every unsigned comparison -- where a quadrant has fewer particles of this class than the
+// longest of the four.  A lane reads its quadrant's slot and record from LDS one step ahead (the four addresses of a wave
+// broadcast inside their 16 lanes) where the whole-patch form read lanes of a register.
+typedef float nc_f4 __attribute__((ext_vector_type(4)));
+// The read pipeline of a lane through its quadrant's padded list: record and slot of the current step, slot of the next one.
+// It runs straight through the class boundaries (the steps of class c + 1 follow those of class c), so a class costs no
+// start-up reads of its own.
+struct NcPipe {
+  nc_f4 r_cur;
+  unsigned s_cur, s_nxt;
+  unsigned o_lds;       // LDS byte address of the current step's entry of this lane's quadrant
+  unsigned p_lds;       // LDS byte address of the staged records
+};
+
+// one step: the record of step i + 1 and the slot of step i + 2 are requested, step i (rec, slot) is worked through, then the
+// wait.  PIPE: requests and wait are inline assembly -- left to itself the compiler folds the pipeline back into "read the
+// slot, wait, read the record, wait" in front of every step (volatile reads become flat loads with a wait each; offsets made
+// opaque get the reads serialised on a shared register).  The wait is tied to the step's last key, so it cannot be scheduled
+// in front of the arithmetic.  Between request and wait the destination registers r_n / s_n2 hold nothing yet: the compiler
+// must not copy or spill them there.  It has no reason to in the common path -- the build checks exactly that on the device
+// assembly of every build (vpower/_asmcheck.py) and refuses to link otherwise -- and the rare paths (further segments of a clump, next to spilling staging code) take
+// the form without assembly (PIPE = false).
+template <int Z0, bool PIPE>
+__device__ __forceinline__ void nc_step(unsigned (&k1)[NC_TZ], unsigned (&k2)[NC_TZ], const float (&qz)[NC_WIN], float qxl, float qyl,
+                                        const nc_f4 rec, const unsigned slot, const unsigned s_nxt, unsigned& o_lds, unsigned p_lds,
+                                        nc_f4& r_n, unsigned& s_n2) {
+  typedef __attribute__((address_space(3))) const nc_f4 lds_f4;
+  typedef __attribute__((address_space(3))) const unsigned short lds_u16;
+  if constexpr (PIPE) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_u16 %1, %3 offset:16"
+                 : "=&v"(r_n), "=&v"(s_n2)
+                 : "v"(p_lds + s_nxt * 16u), "v"(o_lds));   // (beyond a list's end: the padding -- read, not used)
+  } else {
+    r_n = *(lds_f4*)(uintptr_t)(p_lds + s_nxt * 16u);
+    s_n2 = *(lds_u16*)(uintptr_t)(o_lds + 16u);
+  }
+  o_lds += 8;
+  const float fx = qxl - rec.x, fy = qyl - rec.y;
+  const float t2 = fmaf(fy, fy, fx * fx);
+  // (two z per packed instruction -- v_pk_add_f32 / v_pk_fma_f32 -- measured: 14.9 against 14.7 ms, they issue at half rate)
+#pragma unroll
+  for (int k = 0; k < NC_WIN; ++k) {
+    const float fz = qz[k] - rec.z;
+    const float d2 = fmaf(fz, fz, t2);
+    const unsigned key = nc_bfi(NC_SLOTMASK, slot, __float_as_uint(d2));   // (d2 & ~mask) | slot
+    k2[Z0 + k] = nc_umed3(k1[Z0 + k], k2[Z0 + k], key);                  // k1 <= k2: the middle one is the new runner-up
+    k1[Z0 + k] = min(k1[Z0 + k], key);
+  }
+  if constexpr (PIPE) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r_n), "+v"(s_n2), "+v"(k1[Z0 + NC_WIN - 1]));
+}
+
+template <int Z0, bool PIPE>
+__device__ __forceinline__ void nc_run_class(unsigned (&k1)[NC_TZ], unsigned (&k2)[NC_TZ], NcPipe& pp, unsigned beg, unsigned end,
+                                             float qzv, float qxl, float qyl) {
   if (beg >= end) return;   // (wave-uniform)
   float qz[NC_WIN];
 #pragma unroll
-  for (int k = 0; k < NC_WIN; ++k) qz[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qfz[Z0 + k])));
-  unsigned nslot = ord[beg + (unsigned)lane < end ? beg + (unsigned)lane : beg];   // 64 list entries, one per lane
-  float4 nxt = P[nslot];
-  for (unsigned k0 = beg; k0 < end; k0 += 64) {
-    const float4 rec = nxt;
-    const unsigned slotv = nslot;
-    {   // the following 64 entries are requested now and land while these are worked through
-      const unsigned me = k0 + 64u + (unsigned)lane;
-      nslot = ord[me < end ? me : beg];
-      nxt = P[nslot];
+  for (int k = 0; k < NC_WIN; ++k) qz[k] = nc_readlane(qzv, Z0 + k);   // (lane z of qzv holds the tile's z coordinate z)
+  unsigned i = beg;
+  if constexpr (PIPE) {
+    for (; i + 2 <= end; i += 2) {   // two steps per trip: the records alternate between two register sets without copies
+      nc_f4 r_b, r_a;
+      unsigned s_2, s_3;
+      nc_step<Z0, PIPE>(k1, k2, qz, qxl, qyl, pp.r_cur, pp.s_cur, pp.s_nxt, pp.o_lds, pp.p_lds, r_b, s_2);
+      nc_step<Z0, PIPE>(k1, k2, qz, qxl, qyl, r_b, pp.s_nxt, s_2, pp.o_lds, pp.p_lds, r_a, s_3);
+      pp.r_cur = r_a;
+      pp.s_cur = s_2;
+      pp.s_nxt = s_3;
     }
-    const int cnt = __builtin_amdgcn_readfirstlane((int)min(64u, end - k0));   // (scalar: the loop's exit test stays off the VALU)
-    for (int i = 0; i < cnt; ++i) {
-      const float px = nc_readlane(rec.x, i), py = nc_readlane(rec.y, i), pz = nc_readlane(rec.z, i);
-      const unsigned slot = (unsigned)__builtin_amdgcn_readlane((int)slotv, i);
-      const float fx = qxl - px, fy = qyl - py;
-      const float t2 = fmaf(fy, fy, fx * fx);
-      // (two z per packed instruction -- v_pk_add_f32 / v_pk_fma_f32 -- measured: 14.9 against 14.7 ms, they issue at half rate)
-#pragma unroll
-      for (int k = 0; k < NC_WIN; ++k) {
-        const float fz = qz[k] - pz;
-        const float d2 = fmaf(fz, fz, t2);
-        const unsigned key = nc_bfi(NC_SLOTMASK, slot, __float_as_uint(d2));   // (d2 & ~mask) | slot
-        k2[Z0 + k] = nc_umed3(k1[Z0 + k], k2[Z0 + k], key);                  // k1 <= k2: the middle one is the new runner-up
-        k1[Z0 + k] = min(k1[Z0 + k], key);
-      }
-    }
+  }
+  for (; i < end; ++i) {
+    nc_f4 r_b;
+    unsigned s_2;
+    nc_step<Z0, PIPE>(k1, k2, qz, qxl, qyl, pp.r_cur, pp.s_cur, pp.s_nxt, pp.o_lds, pp.p_lds, r_b, s_2);
+    pp.r_cur = r_b;
+    pp.s_cur = pp.s_nxt;
+    pp.s_nxt = s_2;
   }
 }
 
-template <int Z0>
-__device__ __forceinline__ void nc_run_all(unsigned (&k1)[NC_TZ], unsigned (&k2)[NC_TZ],
-                                           const float4* __restrict__ P, const unsigned short* __restrict__ ord,
-                                           const unsigned* __restrict__ cend, const float* __restrict__ qfz, float qxl,
-                                           float qyl, int lane) {
-  const unsigned beg = Z0 ? cend[Z0 - 1] : 0u, end = cend[Z0];
-  nc_run_class<Z0>(k1, k2, P, ord, __builtin_amdgcn_readfirstlane(beg), __builtin_amdgcn_readfirstlane(end), qfz, qxl, qyl, lane);
-  if constexpr (Z0 + 1 < NC_NCLS) nc_run_all<Z0 + 1>(k1, k2, P, ord, cend, qfz, qxl, qyl, lane);
+// cendv: lane c holds the END step of class c (common to the four quadrants)
+template <int Z0, bool PIPE>
+__device__ __forceinline__ void nc_run_all(unsigned (&k1)[NC_TZ], unsigned (&k2)[NC_TZ], NcPipe& pp, unsigned cendv, float qzv,
+                                           float qxl, float qyl) {
+  const unsigned beg = Z0 ? (unsigned)__builtin_amdgcn_readlane((int)cendv, Z0 ? Z0 - 1 : 0) : 0u;
+  const unsigned end = (unsigned)__builtin_amdgcn_readlane((int)cendv, Z0);
+  nc_run_class<Z0, PIPE>(k1, k2, pp, beg, end, qzv, qxl, qyl);
+  if constexpr (Z0 + 1 < NC_NCLS) nc_run_all<Z0 + 1, PIPE>(k1, k2, pp, cendv, qzv, qxl, qyl);
 }
 
 template <typename F, int C>
 __global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __restrict__ pos, const NnScatterParams p) {
   // one LDS block [ P | order | colbase | colg0 ]; the epilogue re-uses its head as the winners' image
-  constexpr int NC_SMEM = NC_SEG * 16 + 4 * NC_SEG * 2 + (NC_MAXCOL + 4) * 4 + NC_MAXCOL * 4;
+  constexpr int NC_PBYTES = (NC_SEG + 1) * 16;           // staged records + the dummy
+  constexpr int NC_SMEM = NC_PBYTES + 4 * NC_SEG * 2 + (NC_MAXCOL + 4) * 4 + NC_MAXCOL * 4;
   constexpr int NC_IMG = 64 * 33;                        // ints per wave: [column][z], one pad word per column
-  static_assert(4 * NC_IMG * 4 <= NC_SEG * 16 + 4 * NC_SEG * 2 + (NC_MAXCOL + 4) * 4, "winner image must fit the staging block");
+  static_assert(4 * NC_IMG * 4 <= NC_SMEM, "winner image must fit the staging block (all of it is dead by the epilogue)");
   __shared__ __attribute__((aligned(16))) unsigned char smem[NC_SMEM];
   float4* P = reinterpret_cast<float4*>(smem);                                         // staged region particles: tile-relative position, index
-  unsigned short (*order)[NC_SEG] = reinterpret_cast<unsigned short (*)[NC_SEG]>(smem + NC_SEG * 16);   // per wave: its particles, sorted by z-window start
-  unsigned* colbase = reinterpret_cast<unsigned*>(smem + NC_SEG * 16 + 4 * NC_SEG * 2);   // [NC_MAXCOL + 4] exclusive prefix of the column run lengths
+  unsigned short (*order)[NC_SEG] = reinterpret_cast<unsigned short (*)[NC_SEG]>(smem + NC_PBYTES);   // per wave: [step][quadrant] staged slots, steps grouped by z-window start
+  unsigned* colbase = reinterpret_cast<unsigned*>(smem + NC_PBYTES + 4 * NC_SEG * 2);   // [NC_MAXCOL + 4] exclusive prefix of the column run lengths
   unsigned* colg0 = colbase + NC_MAXCOL + 4;                                            // [NC_MAXCOL] first record of each column's z run
   __shared__ float qf[3][NC_TZ];                        // lattice coordinates relative to the tile centre
-  __shared__ unsigned cls[4][32];                       // per wave: class counts -> offsets -> ends
+  __shared__ unsigned cls[4][32];                       // per wave: END step of every window class (common to the four quadrants)
+  __shared__ unsigned qcnt[4][4][32];                   // per wave and quadrant: class counts, then write cursors
   __shared__ unsigned wsum[4];
   __shared__ unsigned s_count, s_n;
 
@@ -1244,7 +1294,11 @@ __global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __res
     const int a = tid / NC_TZ, i = tid % NC_TZ;
     qf[a][i] = (float)(ax[a][t0[a] + min(i, nt[a] - 1)] - org[a]);
   }
-  if (tid == 0) s_count = 0;
+  if (tid == 0) {
+    s_count = 0;
+    const float nanf_ = __uint_as_float(0x7fc00000u);
+    P[NC_SEG] = make_float4(nanf_, nanf_, nanf_, __int_as_float(-1));   // the dummy record: every key made from it is a NaN pattern
+  }
   __syncthreads();
 
   // ---- local density -> search radius (as in nn_scatter_kernel), capped by what a window of NC_WIN z-points covers ----
@@ -1311,12 +1365,17 @@ __global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __res
   const int px0 = (wv & 1) * 8, py0 = (wv >> 1) * 8;
   const int ix = px0 + (lane >> 3), iy = py0 + (lane & 7);
   const float qxl = qf[0][min(ix, NC_TX - 1)], qyl = qf[1][min(iy, NC_TY - 1)];
-  float pcx, phx, pcy, phy;   // centre and half extent of the patch (tile-relative)
-  {
-    const float xa = qf[0][px0], xb = qf[0][px0 + 7], ya = qf[1][py0], yb = qf[1][py0 + 7];
-    pcx = 0.5f * (xa + xb); phx = 0.5f * fabsf(xb - xa);
-    pcy = 0.5f * (ya + yb); phy = 0.5f * fabsf(yb - ya);
+  // the patch's four quadrants: x halves a = 0, 1 (columns px0 + 4 a .. + 3), y halves b likewise; centre and half extent
+  // (tile-relative).  A lane's quadrant is 2 a + b of its own column.
+  float qcx[2], qhx[2], qcy[2], qhy[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const float xa = qf[0][px0 + 4 * a], xb = qf[0][px0 + 4 * a + 3], ya = qf[1][py0 + 4 * a], yb = qf[1][py0 + 4 * a + 3];
+    qcx[a] = 0.5f * (xa + xb); qhx[a] = 0.5f * fabsf(xb - xa);
+    qcy[a] = 0.5f * (ya + yb); qhy[a] = 0.5f * fabsf(yb - ya);
   }
+  const int quad = ((lane >> 5) & 1) * 2 + ((lane >> 2) & 1);
+  const float qzv = qf[2][lane & 31];   // the tile's z coordinates, one per lane (read back lane by lane: v_readlane)
   const bool patch_live = px0 < nt[0] && py0 < nt[1];     // (wave-uniform) the patch holds lattice points at all
   const float inv_hz = (float)(1.0 / p.h[2]);
   const float a0z = (float)(p.a0[2] + (double)t0[2] * p.h[2] - org[2]);   // model coordinate of the tile's z index 0
@@ -1410,53 +1469,106 @@ __global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __res
     k2[z] = 0x7f800000u | NC_RESOLVED;
     bi[z] = -1;
   }
-  auto process = [&](const unsigned n) {
+  auto process = [&](const unsigned n, auto pipe_tag) __attribute__((always_inline)) {
+    constexpr bool PIPE = decltype(pipe_tag)::value;
     if (!patch_live || n == 0) return;   // (wave-uniform; stage()'s barriers are reached by every wave all the same)
-    // ---- this wave's list: particles whose R-disc meets the patch, counting-sorted by z-window start ----
-    if (lane < 32) cls[wv][lane] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    auto classify = [&](const float4 q) -> int {   // z-window start, or -1: not this wave's
-      const float dx = fmaxf(fabsf(q.x - pcx) - phx, 0.f), dy = fmaxf(fabsf(q.y - pcy) - phy, 0.f);
-      if (dx * dx + dy * dy > reach * reach) return -1;
+    // ---- this wave's lists: per quadrant the particles whose R-disc meets it, counting-sorted by z-window start; the four
+    // lists share the step axis -- class c takes max over the quadrants of its counts, shorter lists are padded ----
+    auto wave_sync = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // z-window start of a particle, or -1: none of this wave's; `mask`: the quadrants (bit 2 a + b) its disc meets
+    auto classify = [&](const float4 q, unsigned& mask) -> int {
+      mask = 0;
+      float dx2[2], dy2[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const float dx = fmaxf(fabsf(q.x - qcx[a]) - qhx[a], 0.f), dy = fmaxf(fabsf(q.y - qcy[a]) - qhy[a], 0.f);
+        dx2[a] = dx * dx;
+        dy2[a] = dy * dy;
+      }
+      const float r2 = reach * reach;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (dx2[a] + dy2[b] <= r2) mask |= 1u << (2 * a + b);
+      if (!mask) return -1;
       const float u0 = (q.z - Rf - a0z) * inv_hz, u1 = (q.z + Rf - a0z) * inv_hz;
       const int zl = (int)ceilf(fminf(u0, u1) - p.slack[2]), zh = (int)floorf(fmaxf(u0, u1) + p.slack[2]);
       if (zh < 0 || zl > nt[2] - 1) return -1;
       return min(max(zl, 0), NC_NCLS - 1);
     };
-    for (unsigned s_ = lane; s_ < n; s_ += 64) {
-      const int c_ = classify(P[s_]);
-      if (c_ >= 0) atomicAdd(&cls[wv][c_], 1u);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-      const unsigned v = lane < 32 ? cls[wv][lane] : 0u;
-      unsigned incl = v;
-      for (int off = 1; off < 32; off <<= 1) {
-        const unsigned o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
+    unsigned* cnt = &qcnt[wv][0][0];
+    unsigned lo_ = 0;
+    while (lo_ < n) {   // (one trip -- unless a clump makes the lists longer than their LDS room: then the staged range is halved)
+      unsigned hi_ = n, steps;
+      for (;;) {
+        cnt[lane] = 0;
+        cnt[lane + 64] = 0;
+        wave_sync();
+        for (unsigned s_ = lo_ + lane; s_ < hi_; s_ += 64) {
+          unsigned mask;
+          const int c_ = classify(P[s_], mask);
+          if (c_ >= 0) {
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_)
+              if (mask & (1u << q_)) atomicAdd(&cnt[q_ * 32 + c_], 1u);
+          }
+        }
+        wave_sync();
+        {   // class c (lane c): steps = the longest of the four counts; exclusive prefix -> first step; cursors per quadrant
+          const unsigned c0_ = cnt[lane & 31], c1_ = cnt[32 + (lane & 31)], c2_ = cnt[64 + (lane & 31)], c3_ = cnt[96 + (lane & 31)];
+          const unsigned v = lane < NC_NCLS ? max(max(c0_, c1_), max(c2_, c3_)) : 0u;
+          unsigned incl = v;
+          for (int off = 1; off < 32; off <<= 1) {
+            const unsigned o_ = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o_;
+          }
+          steps = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
+          wave_sync();
+          if (lane < 32) {
+            cls[wv][lane] = incl;             // END step of class c
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_) cnt[q_ * 32 + lane] = incl - v;
+          }
+        }
+        if (steps <= (unsigned)NC_SMAX) break;     // (uniform)
+        hi_ = lo_ + (hi_ - lo_) / 2;                // steps <= particles of the range: ends at the latest at NC_SMAX of them
       }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < 32) cls[wv][lane] = incl - v;
+      {   // padding: every entry of the used steps (+ the two read ahead) starts as the dummy slot
+        unsigned* o32 = reinterpret_cast<unsigned*>(order[wv]);
+        const unsigned words = (steps + 2) * 2;
+        for (unsigned w_ = lane; w_ < words; w_ += 64) o32[w_] = (unsigned)NC_SEG | ((unsigned)NC_SEG << 16);
+      }
+      wave_sync();
+      for (unsigned s_ = lo_ + lane; s_ < hi_; s_ += 64) {
+        unsigned mask;
+        const int c_ = classify(P[s_], mask);
+        if (c_ >= 0) {
+#pragma unroll
+          for (int q_ = 0; q_ < 4; ++q_)
+            if (mask & (1u << q_)) order[wv][atomicAdd(&cnt[q_ * 32 + c_], 1u) * 4 + q_] = (unsigned short)s_;
+        }
+      }
+      wave_sync();
+      NC_STAMP(2);
+      // (s_setprio 3 outside the class loops / 0 inside -- so that the latency-bound phases never queue behind another wave's
+      // VALU stream -- measured: 18.5 against 18.4 ms, no effect)
+      {
+        NcPipe pp;
+        const unsigned short* o = order[wv] + quad;
+        pp.p_lds = (unsigned)(size_t)P;
+        pp.o_lds = (unsigned)(size_t)o;
+        pp.s_cur = o[0];
+        pp.s_nxt = o[4];
+        pp.r_cur = *reinterpret_cast<const nc_f4*>(&P[pp.s_cur]);
+        nc_run_all<0, PIPE>(k1, k2, pp, cls[wv][lane & 31], qzv, qxl, qyl);
+      }
+      lo_ = hi_;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (unsigned s_ = lane; s_ < n; s_ += 64) {
-      const int c_ = classify(P[s_]);
-      if (c_ >= 0) order[wv][atomicAdd(&cls[wv][c_], 1u)] = (unsigned short)s_;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // cls[wv][c] now holds the END of class c
-    NC_STAMP(2);
-    // (s_setprio 3 outside the class loops / 0 inside -- so that the latency-bound phases never queue behind another wave's
-    // VALU stream -- measured: 18.5 against 18.4 ms, no effect)
-    nc_run_all<0>(k1, k2, P, order[wv], cls[wv], qf[2], qxl, qyl, lane);
     // winners set in this segment: their particle index, while the staged list still holds it
 #pragma unroll
     for (int z = 0; z < NC_TZ; ++z) {
@@ -1468,12 +1580,12 @@ __global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __res
     }
     NC_STAMP(3);
   };
-  process(staged);
+  process(staged, std::true_type());
   // regions of more than NC_SEG particles (clumps): further segments.  Rare -- and marked so, because staging next to the
   // 96 live accumulators spills, which must not leak into the common path
   while (__builtin_expect(cursor < total, 0)) {
     staged = stage(cursor);
-    process(staged);
+    process(staged, std::false_type());
   }
 
   // ---- epilogue ----

@@ -149,6 +149,9 @@ def build(force=False, verbose=False):
         if stem == "fft":
             # one object per family of line lengths (fft.hip: "translation-unit split"), compiled side by side
             units += [(s, os.path.join(objdir, "fft_p%d.o" % k), ["-DVPS_FFT_PART=%d" % k]) for k in range(FFT_PARTS)]
+        elif stem == "nn":
+            # the device assembly is kept for the static check of the hand-made LDS pipeline (vpower/_asmcheck.py)
+            units.append((s, os.path.join(objdir, stem + ".o"), ["-save-temps=obj"]))
         else:
             units.append((s, os.path.join(objdir, stem + ".o"), []))
     for s, o, extra in units:
@@ -163,6 +166,7 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise VpsError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+    _check_nn_pipeline(objdir, rebuilt=any(c[-1].endswith("nn.o") for c, _ in procs))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
@@ -170,6 +174,37 @@ def build(force=False, verbose=False):
     with open(stamp_path, "w") as f:
         f.write(stamp)
     return LIB_PATH
+
+
+NN_CHECK_REPORT = os.path.join(CSRC, "build", "nn_pipeline_check.json")
+
+
+def _source_sha(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def _check_nn_pipeline(objdir, rebuilt):
+    """nn.hip's column kernel requests LDS reads in one inline-assembly statement and waits for them in another; between the
+    two the destination registers must not be touched.  Checked on the device assembly of THIS build (kept by
+    -save-temps); the verdict is written next to the objects, the temporaries are removed.  A violation stops the build."""
+    import glob, json
+    from . import _asmcheck
+    asm = os.path.join(objdir, "nn-hip-amdgcn-amd-amdhsa-gfx950.s")
+    if rebuilt:
+        if not os.path.exists(asm):
+            raise VpsError("nn.hip was compiled but its device assembly (%s) is missing: cannot check the LDS pipeline" % asm)
+        n, bad = _asmcheck.check(asm)
+        with open(NN_CHECK_REPORT, "w") as f:
+            json.dump({"requests": n, "violations": len(bad), "source_sha16": _source_sha(os.path.join(CSRC, "nn.hip")),
+                       "first": ["line %d: %s: %s" % b for b in bad[:5]]}, f)
+        for tmp in glob.glob(os.path.join(objdir, "nn-hip-*")) + glob.glob(os.path.join(objdir, "nn-host-*")) + \
+                glob.glob(os.path.join(objdir, "nn.hip-hip-*")):
+            os.remove(tmp)
+        if bad or n == 0:
+            raise VpsError("nn.hip: the inline-assembly LDS pipeline is not intact in this build (%d requests, %d violations; %s)"
+                           % (n, len(bad), NN_CHECK_REPORT))
 
 
 _lib = None

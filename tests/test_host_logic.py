@@ -310,3 +310,42 @@ def test_exchange_group_is_closed_on_every_error_path(tmp_path):
     subprocess.run([cxx, "-std=c++17", "-O1", "-Wall", "-Werror", "-I", inc, src, "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+# ------------------------------------------------------------ the NN kernel's hand-made LDS pipeline ----
+def test_asm_pipeline_checker_accepts_a_clean_step_and_rejects_touched_registers(tmp_path):
+    """vpower/_asmcheck.py on synthetic listings: the request/wait pair with arithmetic in between passes; a copy of a
+    destination register, a spill of one, or control flow before the wait are reported."""
+    from vpower import _asmcheck
+    head = "_ZN12_GLOBAL__N_116nn_column_kernelIfLi4EEEvPKT_NS_15NnScatterParamsE:\n"
+    req = "\t;;#ASMSTART\n\tds_read_b128 v[6:9], v5\n\tds_read_u16 v25, v23 offset:16\n\t;;#ASMEND\n"
+    wait = "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n"
+    work = "\tv_sub_f32_e32 v3, s36, v4\n\tv_fma_f32 v3, v3, v3, v2\n\tv_min_u32_e32 v107, v107, v3\n"
+
+    def run(body):
+        f = tmp_path / "k.s"
+        f.write_text(head + body + "\ts_endpgm\n")
+        return _asmcheck.check(str(f))
+
+    assert run(req + work + wait) == (1, [])
+    n, bad = run(req + work + "\tv_mov_b32_e32 v30, v7\n" + wait)                   # copy of a destination register
+    assert n == 1 and len(bad) == 1 and "touches" in bad[0][1]
+    n, bad = run(req + "\tscratch_store_dwordx4 off, v[6:9], off offset:16\n" + work + wait)   # spill
+    assert len(bad) == 1
+    n, bad = run(req + work + "\tv_mov_b32_e32 v25, v1\n" + wait)                   # the slot register overwritten
+    assert len(bad) == 1
+    n, bad = run(req + work + "\ts_cbranch_scc1 .LBB0_1\n" + wait)
+    assert len(bad) == 1 and "control flow" in bad[0][1]
+    # a listing without the kernel's requests is not a pass either (the entry point reports n == 0)
+    assert run(work)[0] == 0
+
+
+def test_built_library_passed_the_pipeline_check():
+    """The build runs the check on the device assembly of nn.hip and leaves its verdict next to the objects: it must be
+    about the sources in the tree and hold no violation (vpower/_ffi.py:_check_nn_pipeline refuses to link otherwise)."""
+    import json
+    from vpower import _ffi
+    _ffi.build()
+    rep = json.load(open(_ffi.NN_CHECK_REPORT))
+    assert rep["violations"] == 0 and rep["requests"] >= 75, rep       # 25 classes x 3 step bodies per instantiation
+    assert rep["source_sha16"] == _ffi._source_sha(os.path.join(_ffi.CSRC, "nn.hip"))
