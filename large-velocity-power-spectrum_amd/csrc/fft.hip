@@ -1446,6 +1446,87 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
 }
 
 // ------------------------------------------------------------------------------
+// Epilogue of the kernels that transform a pencil of TP lines in two halves of TP/2 lines (split pencil, pencil pair): thread
+// (t, l) holds the spectrum of line t in `vpark` and of line t + TP/2 in `v`.  The transposed image of all TP lines does not
+// fit next to nothing else: it is staged in two halves of the mode PAIRS -- the real-to-complex step needs Z[k] with Z[NC - k]:
+// after the last radix-R stage register slot (m, r) holds k = l + L m + r NC/R, so r < R/4 and r >= 3R/4 are exactly the modes
+// k < NC/4 and k >= 3 NC/4 (the pairs of the first half), the middle slots the second.  Z[3 NC/4] pairs with Z[NC/4] of the
+// OTHER half image: the first phase leaves it in `edge` (TP values).  Row kk of a half image: k < NC/4 -> kk = k;
+// k >= 3NC/4 -> kk = k - NC/2 (first half); NC/4 <= k < 3NC/4 -> kk = k - NC/4 (second half).  16-byte stores: two lines per lane.
+// ------------------------------------------------------------------------------
+template <int NC, int TP, int L, bool STREAM>
+__device__ __forceinline__ void two_half_image_store(cf* buf, cf* edge, const cf (&vpark)[NC / L], const cf (&v)[NC / L], int l, int t,
+                                                     int tid, cf* out, cf* nyq, const cf* __restrict__ tw_r2c) {
+  constexpr int RL = NC / L, TH = TP / 2, NT = TH * L, N = 2 * NC;
+  constexpr int R = LastRadix<NC>::R;
+  static_assert((R % 4) == 0 && (NC % 4) == 0, "image in two halves of the mode pairs");
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    int lc = l, tc = t, tidc = tid;
+    asm volatile("" : "+v"(lc), "+v"(tc), "+v"(tidc));
+    lc &= L - 1;
+    tc &= TH - 1;
+    tidc &= NT - 1;
+    __syncthreads();   // exchange buffers / the previous half image are free
+#pragma unroll
+    for (int i = 0; i < RL; ++i) {
+      const int r = i % R;
+      const bool outer = (r < R / 4) || (r >= 3 * R / 4);
+      if (outer == (g == 0)) {
+        const int k = out_index_l<NC, L>(lc, i);
+        const int kk = (g == 0) ? ((r < R / 4) ? k : k - NC / 2) : k - NC / 4;
+        buf[tridx<TP>(kk, tc)] = vpark[i];
+        buf[tridx<TP>(kk, tc + TH)] = v[i];
+        if (g == 0 && i == 3 * R / 4 && lc == 0) {   // slot (m = 0, r = 3R/4) of lane 0: mode 3 NC/4
+          edge[tc] = vpark[i];
+          edge[tc + TH] = v[i];
+        }
+      }
+    }
+    __syncthreads();
+    // pairs of this half: k = 0 .. NC/4 - 1 with NC - k (g = 0; k = 0: the self-paired modes 0 and NC/2 -- NC/2 sits in
+    // the OTHER half image, so g = 0 writes X[0] and the Nyquist plane, g = 1 writes X[NC/2] from its own row);
+    // k = NC/4 .. NC/2 - 1 with NC - k, and the self-paired NC/2 (g = 1)
+    constexpr int H2 = TP / 2, ITEMS = (NC / 4) * H2;
+    static_assert(ITEMS % NT == 0, "whole rounds");
+#pragma unroll 4
+    for (int i = 0; i < ITEMS / NT; ++i) {
+      const int idx = tidc + i * NT;
+      const int tt = (idx % H2) * 2, kq = idx / H2;           // kq = 0 .. NC/4 - 1
+      const int k = (g == 0) ? kq : kq + NC / 4;              // the smaller mode of the pair
+      const int rowk = (g == 0) ? k : k - NC / 4;             // its row in this half image
+      const int rown = (g == 0) ? (NC - k) - NC / 2 : (NC - k) - NC / 4;   // row of NC - k (k > 0)
+      const cf a0 = buf[tridx<TP>(rowk, tt)], a1 = buf[tridx<TP>(rowk, tt + 1)];
+      if (g == 0 && k == 0) {
+        *reinterpret_cast<vps_f4*>(&out[tt]) = vps_f4{a0.x + a0.y, 0.f, a1.x + a1.y, 0.f};
+        *reinterpret_cast<vps_f4*>(&nyq[tt]) = vps_f4{a0.x - a0.y, 0.f, a1.x - a1.y, 0.f};
+      } else {
+        if (g == 1 && k == NC / 4) {
+          // (row NC/2 - NC/4 of this half image holds mode NC/2, which pairs with itself)
+          const cf h0 = buf[tridx<TP>(NC / 2 - NC / 4, tt)], h1 = buf[tridx<TP>(NC / 2 - NC / 4, tt + 1)];
+          *reinterpret_cast<vps_f4*>(&out[(long long)(NC / 2) * N + tt]) = vps_f4{h0.x, -h0.y, h1.x, -h1.y};
+        }
+        const bool at_edge = (g == 1 && k == NC / 4);      // partner 3 NC/4 was left in `edge` by the first phase
+        const cf n0 = at_edge ? edge[tt] : buf[tridx<TP>(rown, tt)], n1 = at_edge ? edge[tt + 1] : buf[tridx<TP>(rown, tt + 1)];
+        const cf w = tw_r2c[k];
+        const cf s0 = make_float2(a0.x + n0.x, a0.y - n0.y), d0 = make_float2(a0.x - n0.x, a0.y + n0.y);
+        const cf s1 = make_float2(a1.x + n1.x, a1.y - n1.y), d1 = make_float2(a1.x - n1.x, a1.y + n1.y);
+        const cf w0 = cmul(w, d0), w1 = cmul(w, d1);
+        const vps_f4 lo = {0.5f * (s0.x + w0.y), 0.5f * (s0.y - w0.x), 0.5f * (s1.x + w1.y), 0.5f * (s1.y - w1.x)};
+        const vps_f4 hi = {0.5f * (s0.x - w0.y), 0.5f * (-s0.y - w0.x), 0.5f * (s1.x - w1.y), 0.5f * (-s1.y - w1.x)};
+        if constexpr (!STREAM) {
+          *reinterpret_cast<vps_f4*>(&out[(long long)k * N + tt]) = lo;
+          *reinterpret_cast<vps_f4*>(&out[(long long)(NC - k) * N + tt]) = hi;
+        } else {
+          __builtin_nontemporal_store(lo, reinterpret_cast<vps_f4*>(&out[(long long)k * N + tt]));
+          __builtin_nontemporal_store(hi, reinterpret_cast<vps_f4*>(&out[(long long)(NC - k) * N + tt]));
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
 // Split pencil: the same pencil (TP = 8 y-lines) on HALF the threads -- a workgroup runs the deposit rounds and the transform of
 // lines 0..3, parks their spectrum in registers (RL values per lane), does the same for lines 4..7, and only then stages the
 // transposed image of all eight lines and stores it.  The LDS region is that of FOUR lines: at 4096-cell lines 67.6 KB instead
@@ -1676,71 +1757,183 @@ __global__ void __launch_bounds__((TP / 2) * pencil_lanes<NC>(), 4) pencil_split
     // ---- image halves: pairs (k, NC - k) with min(k, NC - k) < NC/4 first, the rest second ----
     cf* out = p.out[c] + (long long)x * NC * N + y0;
     cf* nyq = p.nyq[c] + (long long)x * N + y0;
+    two_half_image_store<NC, TP, L, !ENERGY>(buf, edge, vpark, v, l, t, tid, out, nyq, p.tw_r2c);
+  }
+}
+
+// ------------------------------------------------------------------------------
+// Pencil PAIR: two neighbouring 8-line pencils (y0 .. y0 + 7 and y0 + 8 .. y0 + 15 -- consecutive buckets of the sort) in ONE
+// workgroup of the 8-line kernel's shape.  The halves run one after the other through the 8-line kernel's rounds and
+// transform (same LDS region, same threads; each half scans only its own bucket); the first half's spectrum waits in registers,
+// and the epilogue stores the 16 lines together: whole 128-byte lines with 16-byte stores, where two separate pencils wrote 64-byte
+// halves that only sometimes met in L2 (PMC: 117 GB written for 103 GB of output in a vector launch at 2048^3).
+// ------------------------------------------------------------------------------
+template <int NC, bool ENERGY>
+__global__ void __launch_bounds__(8 * pencil_lanes<NC>(), 4) pencil_pair_fft_z_kernel(const PencilParams p) {
+  typedef PlanInfo<NC> PI;
+  constexpr int TH = 8, TP = 16;
+  constexpr int L = pencil_lanes<NC>(), RL = NC / L, NT = TH * L, N = 2 * NC;
+  constexpr int ACC = TH * N;                       // floats of one accumulator (eight lines)
+  constexpr int LINES = TH * PI::PITCH * 2;         // floats of the exchange buffers
+  constexpr int IMG = (NC / 2) * TP * 2;            // floats of half an image: NC/2 modes x 16 lines
+  constexpr int SHARED = (ACC > LINES ? (ACC > IMG ? ACC : IMG) : (LINES > IMG ? LINES : IMG));
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* acc = reinterpret_cast<float*>(smem_raw);
+  cf* buf = reinterpret_cast<cf*>(acc);
+  cf* edge = reinterpret_cast<cf*>(acc + SHARED);
+  cf* tw_lds = edge + TP;
+  constexpr bool TWL = PI::TWLDS;
+  const cf* tw = TWL ? tw_lds : p.tw_stage;
+
+  const int tid = threadIdx.x;
+  const int t = tid / L, l = tid % L;
+  const unsigned nby2 = (unsigned)p.nby / 2u;
+  const unsigned pair = blockIdx.x;
+  const int x = pair / nby2, y0 = (pair % nby2) * TP;
+  const unsigned p0 = (unsigned)x * (unsigned)p.nby + 2u * (pair % nby2);
+  const unsigned sA = p.start[p0], sB = p.start[p0 + 1], eB = p.start[p0 + 2];
+  if constexpr (TWL)
+    for (int i = tid; i < PI::TW; i += NT) tw_lds[i] = p.tw_stage[i];
+  // per half one register-resident record per thread (a bucket of 8 lines holds ~190 records at the bench density, 512
+  // threads); fuller buckets read the rest inside the rounds (tail loops; their per-record value lives in p.side[record])
+  unsigned rloc[2];
+  float rval[2], rrec[2];
+  const unsigned hs[2] = {sA, sB}, he[2] = {sB, eB};
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      int lc = l, tc = t, tidc = tid;
-      asm volatile("" : "+v"(lc), "+v"(tc), "+v"(tidc));
-      lc &= L - 1;
-      tc &= TH - 1;
-      tidc &= NT - 1;
-      __syncthreads();   // exchange buffers / the previous half image are free
-      // row kk of the half image: k < NC/4 -> kk = k; k >= 3NC/4 -> kk = k - NC/2  (g = 0);  NC/4 <= k < 3NC/4 -> kk = k - NC/4 (g = 1)
+  for (int h = 0; h < 2; ++h) {
+    const unsigned j = hs[h] + tid;
+    rloc[h] = (j < he[h]) ? p.records[(size_t)j * 5] : 0xffffffffu;
+    rrec[h] = 1.f;
+  }
+  const bool divide = !ENERGY && p.divide;
+  auto fetch = [&](int h, int word) {   // record word 1..3: rho v_c, 4: rho
+    const unsigned j = hs[h] + tid;
+    if (j < he[h]) rval[h] = __uint_as_float(p.records[(size_t)j * 5 + word]);
+  };
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int R0 = PI::R0, NB0 = RL / R0;
+  constexpr bool WSYNC = (L <= 64) && (64 % L == 0);
+  auto dense_clear = [&]() {
+    for (int i = tid; i < ACC / 4; i += NT) reinterpret_cast<float4*>(acc)[i] = zero4;
+  };
+  auto sparse_clear = [&](int h) {
+    if (rloc[h] != 0xffffffffu) acc[rloc[h]] = 0.f;
+    for (unsigned j = hs[h] + tid + NT; j < he[h]; j += NT) acc[p.records[(size_t)j * 5]] = 0.f;
+  };
+  // one accumulation round of half h: the value in rval[h] (word `word` of the tail records), times 1/rho when dividing
+  auto scatter = [&](int h, int word, bool times_rrec, bool crowded) {
+    if (rloc[h] != 0xffffffffu) vps_lds_add(&acc[rloc[h]], times_rrec ? rval[h] * rrec[h] : rval[h], crowded);
+    for (unsigned j = hs[h] + tid + NT; j < he[h]; j += NT) {
+      const unsigned* rec = p.records + (size_t)j * 5;
+      const float val = __uint_as_float(rec[word]);
+      vps_lds_add(&acc[rec[0]], times_rrec ? val * p.side[j] : val, crowded);
+    }
+  };
+  const bool crowdedh[2] = {(sB - sA) > 2u * (unsigned)ACC, (eB - sB) > 2u * (unsigned)ACC};
+
+  // ---- velocity: 1 / rho of every record's cell; the second half first, so that the accumulator holds the FIRST half's rho
+  // when its first component starts (sparse clear there) ----
+  if (divide) {
+    fetch(1, 4);
+    fetch(0, 4);
 #pragma unroll
-      for (int i = 0; i < RL; ++i) {
-        const int r = i % R;
-        const bool outer = (r < R / 4) || (r >= 3 * R / 4);
-        if (outer == (g == 0)) {
-          const int k = out_index_l<NC, L>(lc, i);
-          const int kk = (g == 0) ? ((r < R / 4) ? k : k - NC / 2) : k - NC / 4;
-          buf[tridx<TP>(kk, tc)] = vpark[i];
-          buf[tridx<TP>(kk, tc + TH)] = v[i];
-          if (g == 0 && i == 3 * R / 4 && lc == 0) {   // slot (m = 0, r = 3R/4) of lane 0: mode 3 NC/4
-            edge[tc] = vpark[i];
-            edge[tc + TH] = v[i];
-          }
-        }
-      }
+    for (int hh = 0; hh < 2; ++hh) {   // (unrolled: h indexes register arrays)
+      const int h = 1 - hh;
       __syncthreads();
-      // pairs of this half: k = 0 .. NC/4 - 1 with NC - k (g = 0; k = 0: the self-paired modes 0 and NC/2 -- NC/2 sits in
-      // the OTHER half image, so g = 0 writes X[0] and the Nyquist plane, g = 1 writes X[NC/2] from its own row);
-      // k = NC/4 .. NC/2 - 1 with NC - k, and the self-paired NC/2 (g = 1)
-      constexpr int H2 = TP / 2, ITEMS = (NC / 4) * H2;
-      static_assert(ITEMS % NT == 0, "whole rounds");
-#pragma unroll 4
-      for (int i = 0; i < ITEMS / NT; ++i) {
-        const int idx = tidc + i * NT;
-        const int tt = (idx % H2) * 2, kq = idx / H2;           // kq = 0 .. NC/4 - 1
-        const int k = (g == 0) ? kq : kq + NC / 4;              // the smaller mode of the pair
-        const int rowk = (g == 0) ? k : k - NC / 4;             // its row in this half image
-        const int rown = (g == 0) ? (NC - k) - NC / 2 : (NC - k) - NC / 4;   // row of NC - k (k > 0)
-        const cf a0 = buf[tridx<TP>(rowk, tt)], a1 = buf[tridx<TP>(rowk, tt + 1)];
-        if (g == 0 && k == 0) {
-          *reinterpret_cast<vps_f4*>(&out[tt]) = vps_f4{a0.x + a0.y, 0.f, a1.x + a1.y, 0.f};
-          *reinterpret_cast<vps_f4*>(&nyq[tt]) = vps_f4{a0.x - a0.y, 0.f, a1.x - a1.y, 0.f};
-        } else {
-          if (g == 1 && k == NC / 4) {
-            // (row NC/2 - NC/4 of this half image holds mode NC/2, which pairs with itself)
-            const cf h0 = buf[tridx<TP>(NC / 2 - NC / 4, tt)], h1 = buf[tridx<TP>(NC / 2 - NC / 4, tt + 1)];
-            *reinterpret_cast<vps_f4*>(&out[(long long)(NC / 2) * N + tt]) = vps_f4{h0.x, -h0.y, h1.x, -h1.y};
-          }
-          const bool at_edge = (g == 1 && k == NC / 4);      // partner 3 NC/4 was left in `edge` by the first phase
-          const cf n0 = at_edge ? edge[tt] : buf[tridx<TP>(rown, tt)], n1 = at_edge ? edge[tt + 1] : buf[tridx<TP>(rown, tt + 1)];
-          const cf w = p.tw_r2c[k];
-          const cf s0 = make_float2(a0.x + n0.x, a0.y - n0.y), d0 = make_float2(a0.x - n0.x, a0.y + n0.y);
-          const cf s1 = make_float2(a1.x + n1.x, a1.y - n1.y), d1 = make_float2(a1.x - n1.x, a1.y + n1.y);
-          const cf w0 = cmul(w, d0), w1 = cmul(w, d1);
-          const vps_f4 lo = {0.5f * (s0.x + w0.y), 0.5f * (s0.y - w0.x), 0.5f * (s1.x + w1.y), 0.5f * (s1.y - w1.x)};
-          const vps_f4 hi = {0.5f * (s0.x - w0.y), 0.5f * (-s0.y - w0.x), 0.5f * (s1.x - w1.y), 0.5f * (-s1.y - w1.x)};
-          if constexpr (ENERGY) {
-            *reinterpret_cast<vps_f4*>(&out[(long long)k * N + tt]) = lo;
-            *reinterpret_cast<vps_f4*>(&out[(long long)(NC - k) * N + tt]) = hi;
-          } else {
-            __builtin_nontemporal_store(lo, reinterpret_cast<vps_f4*>(&out[(long long)k * N + tt]));
-            __builtin_nontemporal_store(hi, reinterpret_cast<vps_f4*>(&out[(long long)(NC - k) * N + tt]));
-          }
-        }
+      dense_clear();
+      __syncthreads();
+      scatter(h, 4, false, crowdedh[h]);
+      __syncthreads();
+      if (rloc[h] != 0xffffffffu) {
+        const float r = acc[rloc[h]];
+        rrec[h] = r != 0.f ? __builtin_amdgcn_rcpf(r) : 0.f;
+      }
+      for (unsigned j = hs[h] + tid + NT; j < he[h]; j += NT) {
+        const float r = acc[p.records[(size_t)j * 5]];
+        p.side[j] = r != 0.f ? __builtin_amdgcn_rcpf(r) : 0.f;
       }
     }
+  }
+
+  const int nfields = ENERGY ? 1 : p.ncomp;
+  for (int c = 0; c < nfields; ++c) {
+    cf vpark[RL], v[RL];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {   // (unrolled: h indexes register arrays)
+      int lc = l, tc = t;
+      asm volatile("" : "+v"(lc), "+v"(tc));   // (keeps the LDS addresses of the two halves from being formed up front)
+      lc &= L - 1;
+      tc &= TH - 1;
+      if constexpr (ENERGY) {
+        // the three rho v_c rounds add up q_c^2 per record, a fourth accumulates rho and finishes E = vol * sum / rho
+        fetch(h, 1 + p.chan[0]);
+        for (int cc = 0; cc < p.ncomp; ++cc) {
+          __syncthreads();
+          if (cc == 0) dense_clear(); else sparse_clear(h);
+          __syncthreads();
+          scatter(h, 1 + p.chan[cc], false, crowdedh[h]);
+          fetch(h, cc + 1 < p.ncomp ? 1 + p.chan[cc + 1] : 4);
+          __syncthreads();
+          if (rloc[h] != 0xffffffffu) {
+            const float q = acc[rloc[h]];
+            rrec[h] = (cc == 0) ? q * q : rrec[h] + q * q;
+          }
+          for (unsigned j = hs[h] + tid + NT; j < he[h]; j += NT) {
+            const float q = acc[p.records[(size_t)j * 5]];
+            p.side[j] = (cc == 0) ? q * q : p.side[j] + q * q;
+          }
+        }
+        __syncthreads();
+        sparse_clear(h);
+        __syncthreads();
+        scatter(h, 4, false, crowdedh[h]);
+        __syncthreads();
+        if (rloc[h] != 0xffffffffu) {
+          const float r = acc[rloc[h]];
+          rrec[h] = r != 0.f ? rrec[h] * __builtin_amdgcn_rcpf(r) * p.vol : 0.f;
+        }
+        for (unsigned j = hs[h] + tid + NT; j < he[h]; j += NT) {
+          const float r = acc[p.records[(size_t)j * 5]];
+          p.side[j] = r != 0.f ? p.side[j] * __builtin_amdgcn_rcpf(r) * p.vol : 0.f;
+        }
+        __syncthreads();
+        if (rloc[h] != 0xffffffffu) acc[rloc[h]] = rrec[h];
+        for (unsigned j = hs[h] + tid + NT; j < he[h]; j += NT) acc[p.records[(size_t)j * 5]] = p.side[j];
+      } else {
+        if (c == 0 && !divide) fetch(h, 1 + p.chan[0]);
+        if (c == 0 && divide && h == 0) {
+          fetch(0, 1 + p.chan[0]);
+          fetch(1, 1 + p.chan[0]);
+        }
+        __syncthreads();   // previous image / the other half's exchange buffers consumed
+        if (divide && c == 0 && h == 0) sparse_clear(0); else dense_clear();
+        __syncthreads();
+        scatter(h, 1 + p.chan[c], divide, crowdedh[h]);
+        if (c + 1 < nfields) fetch(h, 1 + p.chan[c + 1]);
+      }
+      __syncthreads();
+      {
+        const float* q = acc + tc * N;
+        const float sc = (ENERGY || divide) ? 1.f : p.vol;
+#pragma unroll
+        for (int m = 0; m < NB0; ++m)
+#pragma unroll
+          for (int rr = 0; rr < R0; ++rr) {
+            const int j = lc + L * m + rr * (NC / R0);
+            const float2 qq = *reinterpret_cast<const float2*>(q + 2 * j);
+            v[m * R0 + rr] = make_float2(qq.x * sc, qq.y * sc);
+          }
+      }
+      __syncthreads();   // accumulator consumed: its memory becomes FFT scratch
+      fft_from_regs_l<NC, L, WSYNC>(v, buf + tc * PI::PITCH, tw, lc);
+      if (h == 0) {
+#pragma unroll
+        for (int i = 0; i < RL; ++i) vpark[i] = v[i];
+      }
+    }
+    cf* out = p.out[c] + (long long)x * NC * N + y0;
+    cf* nyq = p.nyq[c] + (long long)x * N + y0;
+    two_half_image_store<NC, TP, L, !ENERGY>(buf, edge, vpark, v, l, t, tid, out, nyq, p.tw_r2c);
   }
 }
 
@@ -1793,9 +1986,40 @@ size_t pencil_split_lds_bytes() {
   return shared * sizeof(float) + (size_t)pencil_tp<NC>() * sizeof(cf);
 }
 
+// which launches of 2048-cell lines run as pencil pairs (pencil_pair_fft_z_kernel): bit 0 -- vector launches, bit 1 -- energy
+#ifndef VPS_PENCIL_PAIR
+#define VPS_PENCIL_PAIR 0
+#endif
+template <int NC>
+constexpr int pencil_pair() {
+  return (NC == 1024 && pencil_tp<NC>() == 8 && (LastRadix<NC>::R % 4) == 0) ? (VPS_PENCIL_PAIR) : 0;
+}
+template <int NC>
+size_t pencil_pair_lds_bytes() {
+  typedef PlanInfo<NC> PI;
+  constexpr size_t ACC = (size_t)8 * 2 * NC, LINES = (size_t)8 * PI::PITCH * 2, IMG = (size_t)(NC / 2) * 16 * 2;
+  const size_t shared = ACC > LINES ? (ACC > IMG ? ACC : IMG) : (LINES > IMG ? LINES : IMG);
+  return shared * sizeof(float) + (size_t)16 * sizeof(cf) + (size_t)(PI::TWLDS ? PI::TW : 0) * sizeof(cf);
+}
+
 template <int NC>
 int launch_pencil(vps_ctx* ctx, const PencilParams& p, long long npencils) {
   typedef PlanInfo<NC> PI;
+  if constexpr (pencil_pair<NC>() != 0) if ((pencil_pair<NC>() & (p.energy ? 2 : 1)) && (p.nby % 2) == 0 && npencils % 2 == 0) {
+    const size_t lds2 = pencil_pair_lds_bytes<NC>();
+    auto kern2 = p.energy ? pencil_pair_fft_z_kernel<NC, true> : pencil_pair_fft_z_kernel<NC, false>;
+    if (lds2 > 64 * 1024)
+      VPS_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern2),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    PencilParams pp2 = p;
+    pp2.npencils = (unsigned)npencils;
+    {
+      vps_launch_timer tm(ctx, VPS_K_FFT_Z);
+      hipLaunchKernelGGL(kern2, dim3((unsigned)(npencils / 2)), dim3(8 * pencil_lanes<NC>()), lds2, ctx->stream, pp2);
+    }
+    VPS_HIP_CHECK(ctx, hipGetLastError());
+    return VPS_OK;
+  }
   if constexpr (pencil_split<NC>()) if (p.energy) {   // (the vector form of the split kernel does not fit 128 VGPRs: whole pencils there)
     const size_t lds2 = pencil_split_lds_bytes<NC>();
     constexpr int TP2 = pencil_tp<NC>();
