@@ -906,6 +906,34 @@ def cpu_baseline_legs(cfg):
     return out
 
 
+def hbm_probe(torch, nbytes=4 << 30):
+    """Plain streaming rates of THIS box's HBM through the runtime's own fill and copy kernels (after all timing, workloads
+    freed): what a kernel that only writes (the pencil kernel's stores) or reads and writes (the y pass) a large buffer
+    can hope for at best.  Information beside `roofline`, whose peak stays the guide's 8 TB/s."""
+    try:
+        n = nbytes // 4
+        a = torch.empty(n, dtype=torch.float32, device="cuda")
+        b = torch.empty(n, dtype=torch.float32, device="cuda")
+
+        def timed(f, reps=10):
+            f()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e-3
+        tf, tc = timed(lambda: a.zero_()), timed(lambda: b.copy_(a))
+        del a, b
+        return {"buffer_GB": round(nbytes / 1e9, 2), "fill_GBs": round(nbytes / tf / 1e9, 1),
+                "copy_GBs_read_plus_written": round(2 * nbytes / tc / 1e9, 1),
+                "note": "torch zero_() / copy_() on the bench box; reference points, not the roofline's peak"}
+    except Exception as e:      # (never let a probe take the line down)
+        return {"skipped": repr(e)}
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -1001,6 +1029,8 @@ def main(argv=None):
                                           "particles_per_s_sort_only", "gridding_note", "launch_ms", "nn_query_note") if k in r}
             other[c]["steps"] = 5
         out["other_configs"] = other
+    if single and rank == 0:
+        out["hbm_probe"] = hbm_probe(torch)
     if rank == 0 and single and not args.no_cpu_baseline:
         out.update(cpu_baseline_legs(cfg))
     if rank == 0:
