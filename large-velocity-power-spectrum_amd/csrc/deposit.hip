@@ -868,8 +868,17 @@ __global__ void __launch_bounds__(256)
 }
 
 // LDS tile of one brick: 32 KiB -> four bricks resident per CU, enough workgroups in
-// flight to hide the bucket-read -> LDS-add -> stream-out dependency chain of each one
+// flight to hide the bucket-read -> LDS-add -> stream-out dependency chain of each one.  From 1024^3 on twice that
+// (8 x 8 x 64 cells, two bricks per CU): a brick's stores then cover 64 rows of 256 bytes per field instead of 32, and the
+// sort has half the buckets -- measured (sort + accumulate & write, ms): 1024^3 / 5e7 particles 2.34 + 3.08 against
+// 2.39 + 3.53; 2048^3 / 1e8 4.6 + 16.9 against 5.6 + 20.4 (103 GB written at 6.1 instead of 5.1 TB/s); 512^3 / 1e7 0.37 + 0.36
+// against 0.38 + 0.34; 128 KiB (one brick per CU) 4.8 + 20.4; rows of 512 / 1024 bytes (bz = 128 / 256) 19.0 / 19.4 at 32 KiB.
+#ifndef VPS_BRICK_LDS_BYTES
 #define VPS_BRICK_LDS_BYTES (32 * 1024)
+#endif
+#ifndef VPS_BRICK_BZ
+#define VPS_BRICK_BZ 64
+#endif
 
 int pow2_floor(int v) {
   int p = 1;
@@ -880,8 +889,8 @@ int pow2_floor(int v) {
 Bricks make_bricks(int N, int x0, int nx, int C) {
   Bricks b;
   b.N = N; b.x0 = x0; b.nx = nx;
-  const int max_cells = (VPS_BRICK_LDS_BYTES) / (4 * C);
-  b.bz = N < 64 ? N : 64;                              // up to 256-byte rows
+  const int max_cells = ((N >= 1024 ? 2 : 1) * (VPS_BRICK_LDS_BYTES)) / (4 * C);
+  b.bz = N < VPS_BRICK_BZ ? N : VPS_BRICK_BZ;          // up to 256-byte rows
   if (b.bz > max_cells) b.bz = max_cells;
   int rest = max_cells / b.bz;
   b.by = pow2_floor(rest < 8 ? (rest < 1 ? 1 : rest) : 8);
@@ -959,6 +968,10 @@ DepLayout dep_layout(int64_t np, int C, const Bricks& b, int64_t np_cap = -1) {
   g.nbuckets = l.nbricks;
   g.gshift = 3;
   while (((l.nbricks + (1ll << g.gshift) - 1) >> g.gshift) > sort_target_groups()) ++g.gshift;
+  // more buckets than target x 4096 (the bricks of a 2048^3 grid: 4.2e6): rather more level-1 groups than the
+  // one-atomic-per-particle ranking -- measured at 2048^3 / 1e8 particles: 5.4 ms with 1024 groups against 8.4 ms
+  // (6.2 with 2048 groups, 8.6 with 4096: the group tables grow with them)
+  if (g.gshift > 12 && ((l.nbricks + 4095) >> 12) <= 2048) g.gshift = 12;
   g.ngroups = (int)((l.nbricks + (1ll << g.gshift) - 1) >> g.gshift);
   g.nchunks = (np + SORT_CHUNK - 1) / SORT_CHUNK;     // (slab-sized workspaces: re-set below)
   l.wide_keys = (unsigned long long)l.nbricks * (unsigned long long)b.cells >= 0xffffffffull;
