@@ -714,6 +714,11 @@ __global__ void __launch_bounds__(256)
 // in what both forms share (region set-up, 17 GB of output) -- and its 28 KB of LDS cost the scatter form a workgroup
 // per CU.)
 // ------------------------------------------------------------------------------------------------
+// A tile's search radius is shrunk (x 0.7) until the cell columns of its region fit the staging table.  When the particles are
+// much denser than the lattice (cells narrower than about half a lattice step) the tile's own footprint does not fit at any
+// radius: after this many steps (0.7^40 = 6e-7) the tile gives up and leaves all its points to the exact fallback -- the loop
+// used to have no such exit and would never have ended there.
+constexpr int NN_MAX_SHRINK = 40;
 constexpr int NT_T = 16;                  // lattice tile edge
 constexpr int NT_PTS = NT_T * NT_T * NT_T;
 constexpr int NT_MAXCOL = 1024;           // cell columns of a tile's search region staged in LDS
@@ -836,7 +841,7 @@ __global__ void __launch_bounds__(NT_THREADS) nn_scatter_kernel(const F* __restr
   }
   // region of cells whose particles can lie within R of the tile; shrink R until its columns fit the staging
   int r0[3], r1[3], ncy, ncol;
-  for (;;) {
+  for (int shrink = 0;; ++shrink) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       r0[a] = cell_coord(lo[a] - R, g.lo[a], g.inv_w[a], M);
@@ -845,6 +850,11 @@ __global__ void __launch_bounds__(NT_THREADS) nn_scatter_kernel(const F* __restr
     ncy = r1[1] - r0[1] + 1;
     ncol = (r1[0] - r0[0] + 1) * ncy;
     if (ncol <= NT_MAXCOL) break;
+    if (shrink >= NN_MAX_SHRINK) {   // the tile ALONE covers more cell columns than can be staged (particles far denser than the
+      R = 0.0;                       // lattice): no region, every point of the tile goes to the exact fallback
+      ncol = 0;
+      break;
+    }
     R *= 0.7;
   }
   const float Rf = (float)R;
@@ -1325,7 +1335,7 @@ __global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __res
     R = nc_radius(g, c0, c1, s_count, p.kappa, p.slack[2], p.h[2]);
   }
   int r0[3], r1[3], ncy, ncol;
-  for (;;) {
+  for (int shrink = 0;; ++shrink) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       r0[a] = cell_coord(lo[a] - R, g.lo[a], g.inv_w[a], M);
@@ -1334,6 +1344,11 @@ __global__ void __launch_bounds__(NC_THREADS, 4) nn_column_kernel(const F* __res
     ncy = r1[1] - r0[1] + 1;
     ncol = (r1[0] - r0[0] + 1) * ncy;
     if (ncol <= NC_MAXCOL) break;
+    if (shrink >= NN_MAX_SHRINK) {   // the tile ALONE covers more cell columns than can be staged (particles far denser than the
+      R = 0.0;                       // lattice): no region, every point of the tile goes to the exact fallback
+      ncol = 0;
+      break;
+    }
     R *= 0.7;
   }
   const float Rf = (float)R;

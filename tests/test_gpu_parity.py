@@ -162,6 +162,25 @@ def test_nn_index_matches_oracle(Np, N, dtype):
     assert np.array_equal(idx.ravel(), ref)
 
 
+@pytest.mark.parametrize("kernel", ["column", "scatter"])
+def test_nn_particles_far_denser_than_the_lattice(kernel):
+    """~100 particles per lattice cell: the cells of the particle list are a quarter of a lattice step wide, and a 16 x 16 tile
+    alone covers more cell columns than a workgroup can stage at ANY search radius.  The tile kernels then give up (their
+    radius-shrinking loop has an exit since round 4 -- it used to spin forever here) and leave the tile to the exact
+    fallback: indices bit exact all the same, for the column-register kernel and (forced) the scatter kernel."""
+    from vpower import interp, _ffi
+    Np, N = 400000, 16
+    rng = np.random.default_rng(99)
+    pos = rng.random((Np, 3)).astype(np.float32)
+    ax = orc.lattice_axes_library(1.0, N)
+    _ffi.set_option("nn_column", 1 if kernel == "column" else 0)
+    try:
+        idx = interp.nn_index(pos, (ax, ax, ax))
+    finally:
+        _ffi.set_option("nn_column", None)
+    assert np.array_equal(idx.ravel(), orc.exact_nn_lattice(pos, ax, ax, ax))
+
+
 def test_nn_ties_lowest_index_and_duplicates():
     from vpower import interp
     pos = np.array([[0.25, 0.5, 0.5], [0.75, 0.5, 0.5], [0.75, 0.5, 0.5], [0.25, 0.5, 0.5]], dtype=np.float64)
