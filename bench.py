@@ -325,11 +325,16 @@ class Workload:
             token = None
             self.pipe.prepare()
             accs = self._quantity_accs()
+            # momentum and, later in the step, kinetic energy: the momentum launch leaves the energy field's z image behind as
+            # well (its rounds accumulate the cell totals of rho v_c that field is made of; device.Kernels.deposit_fft_zy)
+            share = ("momentum" in self.quantities and "energy" in self.quantities
+                     and self.quantities.index("momentum") < self.quantities.index("energy")
+                     and os.environ.get("VPS_SHARE_ENERGY") != "0")
             for i, q in enumerate(self.quantities):
                 qi, nc = dev.QUANTITY[q], NCOMP[q]
                 with K.binning_only():
                     spec, nyq = K.deposit_fft_zy(self.pos, self.vel, self.rho, N, L, x0, nx, qi,
-                                                 spec=self.spec[:nc], nyq=self.nyq[:nc], reuse_sort=token)
+                                                 spec=self.spec[:nc], nyq=self.nyq[:nc], reuse_sort=token, share_energy=share)
                 token = K.fused_token()
                 self.pipe.accumulate_spectra(spec, nyq, accs[i][1], accs[i][2])
             return self._quantity_tables(accs)
@@ -690,7 +695,8 @@ def run_config(args, cfg, K, comm, world, rank, backend, steps, warmup, profile_
             wl.acc_buf = pall._acc_buf
             tall = wl.step()
             wl.pipe, (wl.psum, wl.nsample, wl.acc_buf) = keep_pipe, keep_acc
-            want = chk.parseval_targets(chk.ngp_moments_float64(dpos, dvel, drho, N, L, quantities), N)
+            # (x-slabs of 32 planes at 2048^3: ten float64 arrays of a slab are alive at once -- 11 GB instead of 43 next to the workload)
+            want = chk.parseval_targets(chk.ngp_moments_float64(dpos, dvel, drho, N, L, quantities, rows=32 if N >= 2048 else 128), N)
             worst = 0.0
             for q in quantities:
                 t_ = tall[q]
@@ -1029,6 +1035,13 @@ def main(argv=None):
                                           "particles_per_s_sort_only", "gridding_note", "launch_ms", "nn_query_note") if k in r}
             other[c]["steps"] = 5
         out["other_configs"] = other
+    if rank == 0:
+        # device memory: the library's buffers are torch allocations (device.Kernels.empty / workspace), so torch's own
+        # high-water mark covers them; the driver's free / total as a cross-check
+        free_b, total_b = torch.cuda.mem_get_info()
+        out["device_memory"] = {"peak_allocated_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+                                "peak_reserved_GB": round(torch.cuda.max_memory_reserved() / 1e9, 2),
+                                "total_GB": round(total_b / 1e9, 2)}
     if single and rank == 0:
         out["hbm_probe"] = hbm_probe(torch)
     if rank == 0 and single and not args.no_cpu_baseline:

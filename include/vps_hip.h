@@ -50,6 +50,15 @@ enum vps_quantity { VPS_VELOCITY = 0, VPS_MOMENTUM = 1, VPS_ENERGY = 2,
 #define VPS_FLAG_REUSE_SORT 4              /* vps_deposit_fft_zy: work_dev still holds the bucketed records of the
                                               previous call with the SAME particles, N, Lbox, x0, nx -- skip the sort
                                               (several quantities of one snapshot) */
+#define VPS_FLAG_SHARE_ENERGY 8            /* vps_deposit_fft_zy / vps_deposit_fft_z[_slab], momentum and kinetic energy of ONE snapshot:
+                                              on the VPS_MOMENTUM call (all three components, no VPS_FLAG_REFERENCE_MOMENTUM_BUG) the
+                                              launch ALSO leaves the z image of the energy field E = mass |v|^2 -- made of the same cell
+                                              totals of rho v_c -- as a FOURTH component (workspace sized by
+                                              vps_deposit_fft_zy_workspace_bytes_shared; a zimg_dev of four components); on the following
+                                              VPS_ENERGY call (with VPS_FLAG_REUSE_SORT: same particles, N, Lbox, x0, nx, same
+                                              workspace / zimg_dev) nothing is deposited: vps_deposit_fft_zy runs the y pass of that
+                                              component, vps_deposit_fft_z[_slab] returns at once (the caller reads component 3).
+                                              Same numbers as the energy launch of its own up to the order of float32 additions. */
 
 #define VPS_FLAG_COMPONENTS(mask) (((mask) & 7) << 4) /* vps_deposit_fft_zy / vps_deposit_fft_z[_slab], velocity or momentum: produce
                                               ONLY the components in `mask` (bit c = component c; 0 = all three), in ascending
@@ -65,7 +74,7 @@ int vps_destroy(vps_ctx* ctx);
 const char* vps_last_error(const vps_ctx* ctx);   /* ctx may be NULL: global slot */
 int vps_set_stream(vps_ctx* ctx, void* hip_stream);
 int vps_sync(vps_ctx* ctx);
-#define VPS_ABI_VERSION 5
+#define VPS_ABI_VERSION 6
 int vps_version(void);                            /* ABI version (VPS_ABI_VERSION)  */
 /* Tuning / test switches, process-wide.  The library never reads the environment: a stray variable in a user's job cannot
  * change a code path; the host sets what it wants explicitly (vpower/_ffi.py maps VPS_OPT_<NAME> variables once, at load,
@@ -168,6 +177,7 @@ int vps_deposit_field(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const f
  *   spec_dev [ncomp][N/2][N][nx] complex64,  nyq_dev [ncomp][N][nx] complex64.
  * work_dev: vps_deposit_fft_zy_workspace_bytes(np, N, nx).                          */
 int vps_deposit_fft_zy_supported(vps_ctx* ctx, int N, int quantity);
+size_t vps_deposit_fft_zy_workspace_bytes_shared(int64_t np, int N, int nx);   /* ... with room for the fourth z image of VPS_FLAG_SHARE_ENERGY */
 size_t vps_deposit_fft_zy_workspace_bytes(int64_t np, int N, int nx);
 int vps_deposit_fft_zy(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
                        const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx,

@@ -1268,6 +1268,11 @@ size_t vps_deposit_fft_zy_workspace_bytes(int64_t np, int N, int nx) {
   return sort + images;
 }
 
+size_t vps_deposit_fft_zy_workspace_bytes_shared(int64_t np, int N, int nx) {
+  const size_t base = vps_deposit_fft_zy_workspace_bytes(np, N, nx);
+  return base ? base + ((size_t)nx * (N / 2) * N + (size_t)nx * N) * sizeof(float2) : 0;
+}
+
 static int deposit_fft_impl(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, const float* vel_dev,
                             const float* rho_dev, int64_t np, int N, double Lbox, int x0, int nx, int quantity,
                             int flags, void* spec_dev, void* nyq_dev, void* zimg_dev, void* work_dev, int64_t np_cap = -1);
@@ -1364,6 +1369,13 @@ static int deposit_fft_impl(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, c
   int chan[3] = {0, bug ? 0 : 1, bug ? 0 : 2};
   int ncomp = 3;
   const int only = (flags & VPS_FLAG_COMPONENT_MASK) >> 4;   // bit c: component c is wanted (VPS_FLAG_COMPONENTS); 0: all
+  int with_energy = 0;    // VPS_FLAG_SHARE_ENERGY: 1 the momentum launch that also makes the energy field, 2 the energy call that uses it
+  if (flags & VPS_FLAG_SHARE_ENERGY) {
+    if (quantity == VPS_MOMENTUM && !bug && !only) with_energy = 1;
+    else if (quantity == VPS_ENERGY && (flags & VPS_FLAG_REUSE_SORT)) with_energy = 2;
+    else return vps_fail(ctx, VPS_ERR_ARG, "VPS_FLAG_SHARE_ENERGY: a whole momentum field (no component mask, no reference bug), then "
+                                           "the energy field with VPS_FLAG_REUSE_SORT");
+  }
   if (only) {
     if (quantity == VPS_ENERGY) return vps_fail(ctx, VPS_ERR_ARG, "vps_deposit_fft_zy: VPS_FLAG_COMPONENTS with the (scalar) energy field");
     const int all[3] = {chan[0], chan[1], chan[2]};
@@ -1375,7 +1387,7 @@ static int deposit_fft_impl(vps_ctx* ctx, const void* pos_dev, int pos_is_f64, c
   return vps_fft_pencil_zy(ctx, N, nx, reinterpret_cast<const unsigned*>(work + l.records),
                            reinterpret_cast<const unsigned*>(work + l.start), reinterpret_cast<float*>(work + l.ranks), ncomp, chan,
                            quantity == VPS_MOMENTUM ? 0 : 1, quantity == VPS_ENERGY ? 1 : 0, (float)(lc * lc * lc),
-                           spec_dev, nyq_dev, zimg_dev ? zimg_dev : (void*)(work + l.total));
+                           spec_dev, nyq_dev, zimg_dev ? zimg_dev : (void*)(work + l.total), with_energy);
 }
 
 int vps_density_velocity_vector(vps_ctx* ctx, const float* vel_dev, const float* rho_dev, int64_t np,

@@ -1072,10 +1072,13 @@ struct PencilParams {
   int chan[3];               // record channel (0..2) feeding component c
   int divide;                // 1: v = q / rho (0 where rho == 0);  0: p = q * vol
   int energy;                // 1: ONE output field E = vol * sum_c q_c^2 / rho (= mass * |v|^2, interp.py:546)
+  int with_energy;           // momentum launch (divide = 0, three components) that ALSO writes the energy field as out[3]: the
+                             // cell totals of rho v_c its rounds accumulate are what E is made of -- one more round (rho) and
+                             // one more transform instead of a launch of its own with four rounds and a start of its own
   float vol;
   float* side;               // [records] one float per record, for the records a workgroup cannot keep in registers
-  cf* out[3];                // B_c[x][kz][y]
-  cf* nyq[3];                // BN_c[x][y]
+  cf* out[4];                // B_c[x][kz][y]
+  cf* nyq[4];                // BN_c[x][y]
   const cf* tw_stage;
   const cf* tw_r2c;
 };
@@ -1295,7 +1298,8 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
 
   // ENERGY: the three rho*v_c rounds add up q_c^2 per record, a FOURTH round accumulates rho and finishes
   // E = vol * sum / rho in the cells that hold records (all others stay 0)
-  const int nround = ENERGY ? p.ncomp + 1 : p.ncomp;
+  const bool we = !ENERGY && p.with_energy;     // (uniform) momentum launch that also produces the energy field
+  const int nround = (ENERGY || we) ? p.ncomp + 1 : p.ncomp;
   for (int c = 0; c < nround; ++c) {
     // opaque copies: keeps the compiler from hoisting ~50 loop-invariant LDS addresses out of the
     // component loop (they cost more registers than they save instructions, and an occupancy step)
@@ -1329,7 +1333,7 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
 #endif
     }
     if (!prezeroed) __syncthreads();
-    const bool rho_round = ENERGY && c == p.ncomp;
+    const bool rho_round = (ENERGY || we) && c == p.ncomp;
     const int word = rho_round ? 4 : 1 + p.chan[c < p.ncomp ? c : 0];
     // velocity: each term is divided by its cell's rho as it is added -- sum_k (q_k / rho) for the reference's
     // (sum_k q_k) / rho: a different rounding of the same value, within the float32 accumulation noise of the sums
@@ -1338,14 +1342,14 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
     for (int k = 0; k < KR; ++k)
       if (rloc[k] != 0xffffffffu) vps_lds_add(&acc[rloc[k]], divide ? rval[k] * rrec[k] : rval[k], crowded);
 #endif
-    if (c + 1 < nround) fetch((ENERGY && c + 1 == p.ncomp) ? 4 : 1 + p.chan[c + 1 < p.ncomp ? c + 1 : 0]);
+    if (c + 1 < nround) fetch(((ENERGY || we) && c + 1 == p.ncomp) ? 4 : 1 + p.chan[c + 1 < p.ncomp ? c + 1 : 0]);
     for (unsigned j = tail0; j < e; j += NT) {
       const unsigned* rec = p.records + (size_t)j * 5;
       const float val = __uint_as_float(rec[word]);
       vps_lds_add(&acc[rec[0]], divide ? val * p.side[j] : val, crowded);
     }
     __syncthreads();
-    if constexpr (ENERGY) {
+    if (ENERGY || we) {
       if (!rho_round) {
         // the cell totals of this component, squared, per record
 #pragma unroll
@@ -1358,32 +1362,34 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
           const float q = acc[p.records[(size_t)j * 5]];
           p.side[j] = (c == 0) ? q * q : p.side[j] + q * q;
         }
-        continue;   // (the barrier at the top of the loop protects the accumulator)
-      }
-      // the accumulator holds rho: E = sum * (1 / rho) * vol where there is mass, 0 elsewhere -- every record writes its cell's
-      // value (records of one cell write the same bits), after everybody has read rho
+        if constexpr (ENERGY) continue;   // (the barrier at the top of the loop protects the accumulator)
+        // (with_energy: the accumulator goes on into this component's own transform)
+      } else {
+        // the accumulator holds rho: E = sum * (1 / rho) * vol where there is mass, 0 elsewhere -- every record writes its cell's
+        // value (records of one cell write the same bits), after everybody has read rho
 #pragma unroll
-      for (int k = 0; k < KR; ++k)
-        if (rloc[k] != 0xffffffffu) {
-          const float r = acc[rloc[k]];
-          rrec[k] = r != 0.f ? rrec[k] * __builtin_amdgcn_rcpf(r) * p.vol : 0.f;
+        for (int k = 0; k < KR; ++k)
+          if (rloc[k] != 0xffffffffu) {
+            const float r = acc[rloc[k]];
+            rrec[k] = r != 0.f ? rrec[k] * __builtin_amdgcn_rcpf(r) * p.vol : 0.f;
+          }
+        for (unsigned j = tail0; j < e; j += NT) {
+          const float r = acc[p.records[(size_t)j * 5]];
+          p.side[j] = r != 0.f ? p.side[j] * __builtin_amdgcn_rcpf(r) * p.vol : 0.f;
         }
-      for (unsigned j = tail0; j < e; j += NT) {
-        const float r = acc[p.records[(size_t)j * 5]];
-        p.side[j] = r != 0.f ? p.side[j] * __builtin_amdgcn_rcpf(r) * p.vol : 0.f;
-      }
-      __syncthreads();
+        __syncthreads();
 #pragma unroll
-      for (int k = 0; k < KR; ++k)
-        if (rloc[k] != 0xffffffffu) acc[rloc[k]] = rrec[k];
-      for (unsigned j = tail0; j < e; j += NT) acc[p.records[(size_t)j * 5]] = p.side[j];
-      __syncthreads();
+        for (int k = 0; k < KR; ++k)
+          if (rloc[k] != 0xffffffffu) acc[rloc[k]] = rrec[k];
+        for (unsigned j = tail0; j < e; j += NT) acc[p.records[(size_t)j * 5]] = p.side[j];
+        __syncthreads();
+      }
     }
     // stage-0 inputs straight from the accumulator: z[j] = f[2j] + i f[2j+1]
     cf v[RL];
     {
       const float* q = acc + tc * N;
-      const float sc = (ENERGY || divide) ? 1.f : p.vol;
+      const float sc = (ENERGY || divide || rho_round) ? 1.f : p.vol;
 #pragma unroll
       for (int m = 0; m < NB0; ++m)
 #pragma unroll
@@ -2005,7 +2011,7 @@ size_t pencil_pair_lds_bytes() {
 template <int NC>
 int launch_pencil(vps_ctx* ctx, const PencilParams& p, long long npencils) {
   typedef PlanInfo<NC> PI;
-  if constexpr (pencil_pair<NC>() != 0) if ((pencil_pair<NC>() & (p.energy ? 2 : 1)) && (p.nby % 2) == 0 && npencils % 2 == 0) {
+  if constexpr (pencil_pair<NC>() != 0) if ((pencil_pair<NC>() & (p.energy ? 2 : 1)) && !p.with_energy && (p.nby % 2) == 0 && npencils % 2 == 0) {
     const size_t lds2 = pencil_pair_lds_bytes<NC>();
     auto kern2 = p.energy ? pencil_pair_fft_z_kernel<NC, true> : pencil_pair_fft_z_kernel<NC, false>;
     if (lds2 > 64 * 1024)
@@ -3283,7 +3289,11 @@ bool vps_pencil_supported(vps_ctx* ctx, int N) {
 // z images [component][B | BN] stay in bwork_dev)
 int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, const unsigned* start, float* side,
                       int ncomp, const int* chan, int divide, int energy, float vol, void* spec_dev, void* nyq_dev,
-                      void* bwork_dev) {
+                      void* bwork_dev, int with_energy) {
+  // with_energy = 1: a momentum launch (three components) that leaves the energy field's z image as component 3 of bwork_dev;
+  // with_energy = 2: no launch -- the y pass of that component 3 (the energy quantity of a step whose momentum launch made it)
+  if (with_energy && (energy != (with_energy == 2) || divide != (with_energy == 2 ? 1 : 0) || (with_energy == 1 && ncomp != 3)))
+    return vps_fail(ctx, VPS_ERR_ARG, "vps_fft_pencil_zy: the shared energy field needs an undivided three-component momentum launch");
   const int NH = N / 2;
   vps_fft_tables tz;
   int rc = vps_fft_get_tables(ctx, NH, &tz);
@@ -3298,21 +3308,27 @@ int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, cons
   p.nx = nx;
   p.nby = N / vps_pencil_tp(N);
   p.ncomp = ncomp;
-  for (int c = 0; c < 3; ++c) {
-    p.chan[c] = chan[c < ncomp ? c : 0];
+  for (int c = 0; c < 3; ++c) p.chan[c] = chan[c < ncomp ? c : 0];
+  for (int c = 0; c < 4; ++c) {
     p.out[c] = Bbase + (size_t)c * (bfield + bnyq);
     p.nyq[c] = p.out[c] + bfield;
   }
   p.divide = divide;
   p.energy = energy;
+  p.with_energy = with_energy == 1;
   p.vol = vol;
   p.tw_stage = tz.tw_stage;
   p.tw_r2c = tz.tw_r2c;
   const long long npencils = (long long)nx * p.nby;
-  rc = route_pencil(ctx, NH, p, npencils);
-  if (rc || !spec_dev) return rc;
+  if (with_energy != 2) {
+    rc = route_pencil(ctx, NH, p, npencils);
+    if (rc) return rc;
+  }
+  if (!spec_dev) return VPS_OK;
   cf* spec = reinterpret_cast<cf*>(spec_dev);
   cf* nyq = reinterpret_cast<cf*>(nyq_dev);
+  if (with_energy == 2)      // the z image the momentum launch left as component 3
+    return fft_y_of(ctx, N, nx, p.out[3], p.nyq[3], spec, nyq);
   const int nout = energy ? 1 : ncomp;
   for (int c = 0; c < nout; ++c) {
     rc = fft_y_of(ctx, N, nx, p.out[c], p.nyq[c], spec + (size_t)c * NH * N * nx, nyq + (size_t)c * N * nx);

@@ -128,7 +128,7 @@ bool vps_pencil_supported(vps_ctx* ctx, int N);
 // side: one float per record (scratch of the kernel: what it keeps per record when a bucket outgrows its registers)
 int vps_fft_pencil_zy(vps_ctx* ctx, int N, int nx, const unsigned* records, const unsigned* start, float* side,
                       int ncomp, const int* chan, int divide, int energy, float vol, void* spec_dev, void* nyq_dev,
-                      void* bwork_dev);
+                      void* bwork_dev, int with_energy = 0);
 
 // ---- LDS floating-point accumulation ---------------------------------------------------------
 // gfx950 executes ds_add_f32 far below the LDS rate (measured: about one lane every two clocks per

@@ -52,6 +52,7 @@ SYMBOLS = (
                                     C.c_int, C.c_int, C.c_int, _vp, _vp)),
     ("vps_deposit_fft_zy_supported", C.c_int, (_vp, C.c_int, C.c_int)),
     ("vps_deposit_fft_zy_workspace_bytes", C.c_size_t, (_i64, C.c_int, C.c_int)),
+    ("vps_deposit_fft_zy_workspace_bytes_shared", C.c_size_t, (_i64, C.c_int, C.c_int)),
     ("vps_deposit_fft_zy", C.c_int, (_vp, _vp, C.c_int, _vp, _vp, _i64, C.c_int, C.c_double, C.c_int, C.c_int,
                                      C.c_int, C.c_int, _vp, _vp, _vp)),
     ("vps_density_velocity_vector", C.c_int, (_vp, _vp, _vp, _i64, _vp)),
@@ -111,7 +112,7 @@ KERNEL_KINDS = {"deposit": K_DEPOSIT, "algebra": K_ALGEBRA, "fft_z": K_FFT_Z, "f
                 "exchange": K_EXCHANGE, "exchange_wait": K_EXCHANGE_WAIT}
 
 
-ABI_VERSION = 5   # include/vps_hip.h: VPS_ABI_VERSION
+ABI_VERSION = 6   # include/vps_hip.h: VPS_ABI_VERSION
 FFT_PARTS = 4   # fft.hip is compiled once per family of line lengths (-DVPS_FFT_PART=k)
 
 

@@ -33,6 +33,7 @@ QUANTITY = {"velocity": VELOCITY, "momentum": MOMENTUM, "energy": ENERGY}
 FLAG_REFERENCE_MOMENTUM_BUG = 1
 FLAG_INPUT_IS_VM = 2
 FLAG_REUSE_SORT = 4
+FLAG_SHARE_ENERGY = 8
 
 
 # --------------------------------------------------------------------------- #
@@ -297,11 +298,15 @@ class HipKernels:
         return bool(self.lib.vps_deposit_fft_zy_supported(self.ctx, int(N), int(quantity)))
 
     def deposit_fft_zy(self, pos, vel, rho, N, Lbox, x0, nx, quantity, flags=0, spec=None, nyq=None, reuse_sort=None,
-                       component=None):
+                       component=None, share_energy=False):
         """Fused deposit + field algebra + z/y passes:
         -> spec [ncomp, N/2, N, nx], nyq [ncomp, N, nx] (complex64); ncomp = 1 for ENERGY, else 3.
         component = 0..2, or a collection of them: only those components of a velocity / momentum field, in ascending order
-        (ncomp = their number; VPS_FLAG_COMPONENTS)."""
+        (ncomp = their number; VPS_FLAG_COMPONENTS).
+        share_energy (pass it on EVERY call of a step that asks for momentum and, later, kinetic energy): the workspace gets room
+        for a fourth z image; the momentum launch -- whose rounds accumulate the very cell totals of rho v_c the energy field is
+        made of -- leaves that field's z image there as well (VPS_FLAG_SHARE_ENERGY), and the energy call that follows it with a
+        valid reuse_sort token only runs its y pass.  Any other order of calls simply launches the energy kernel as usual."""
         self._stream()
         ncomp = 1 if quantity == ENERGY else 3
         if component is not None:
@@ -312,8 +317,17 @@ class HipKernels:
             spec = self.empty((ncomp, N // 2, N, nx), torch.complex64)
         if nyq is None:
             nyq = self.empty((ncomp, N, nx), torch.complex64)
-        work = self.workspace("fused", self.lib.vps_deposit_fft_zy_workspace_bytes(pos.shape[0], N, nx))
+        size_of = self.lib.vps_deposit_fft_zy_workspace_bytes_shared if share_energy else self.lib.vps_deposit_fft_zy_workspace_bytes
+        work = self.workspace("fused", size_of(pos.shape[0], N, nx))
         flags |= self._reuse_flag(reuse_sort, pos, vel, rho, N, Lbox, x0, nx, work)
+        shared_by = getattr(self, "_energy_shared_by", None)     # token of the momentum call that left the energy z image behind
+        self._energy_shared_by = None
+        if share_energy and component is None:
+            if quantity == MOMENTUM and not (flags & FLAG_REFERENCE_MOMENTUM_BUG):
+                flags |= FLAG_SHARE_ENERGY
+                self._energy_shared_by = self._fused_token
+            elif quantity == ENERGY and (flags & FLAG_REUSE_SORT) and shared_by is not None and reuse_sort is shared_by:
+                flags |= FLAG_SHARE_ENERGY
         self._chk(self.lib.vps_deposit_fft_zy(self.ctx, self._ptr(pos), self._pos_kind(pos),
                                               self._ptr(vel, torch.float32), self._ptr(rho, torch.float32),
                                               pos.shape[0], N, float(Lbox), x0, nx, quantity, flags,

@@ -123,6 +123,61 @@ def test_fused_deposit_fft_zy_thin_slab_against_oracle(K, N, nx, x0, quantity):
     _free(K)
 
 
+@pytest.mark.parametrize("N,nx,x0", [(512, 16, 40), (2048, 16, 1000), (4096, 8, 4088)])
+def test_momentum_launch_shares_the_energy_field(K, N, nx, x0):
+    """VPS_FLAG_SHARE_ENERGY: the momentum launch of a step leaves the z image of E = mass |v|^2 behind as a fourth component
+    (made of the cell totals its own rounds accumulate); the energy call that follows runs no deposit launch at all.  Against the
+    ORACLE-deposited slab (momentum and energy), against the energy launch of its own, and: any other order of calls falls back
+    to that launch."""
+    from vpower import device
+    L = 1.0
+    rng = np.random.default_rng(N + x0 + 1)
+    Np = 500_000
+    pos = rng.random((Np, 3), dtype=np.float32)
+    pos[: Np // 2, 0] = (x0 + rng.random(Np // 2, dtype=np.float32) * nx) / N
+    pos[: Np // 8, 1:] *= 0.05                                      # a crowded corner: pencils that outgrow their registers
+    vel = rng.standard_normal((Np, 3), dtype=np.float32)
+    dens = np.exp(0.5 * rng.standard_normal(Np)).astype(np.float32)
+    dpos, dvel, drho = K.to_device(pos), K.to_device(vel), K.to_device(dens)
+
+    def check(spec, nyq, quantity, tol=1e-5):
+        fields = _oracle_slab_fields(pos, vel, dens, N, L, x0, nx, quantity)
+        for c, f in enumerate(fields):
+            ref = np.fft.fft(np.fft.rfft(f, axis=2), axis=1)            # [x, ky, kz <= N/2]
+            scale = np.sqrt(np.mean(np.abs(ref) ** 2))
+            err = np.max(np.abs(spec[c].cpu().numpy().transpose(2, 1, 0) - ref[:, :, : N // 2]))
+            errn = np.max(np.abs(nyq[c].cpu().numpy().T - ref[:, :, N // 2]))
+            assert err / scale < tol and errn / scale < tol, (quantity, c, err / scale, errn / scale)
+
+    own, own_n = K.deposit_fft_zy(dpos, dvel, drho, N, L, x0, nx, device.ENERGY)           # the energy launch of its own
+    own, own_n = own.clone(), own_n.clone()
+    K.deposit_fft_zy(dpos, dvel, drho, N, L, x0, nx, device.VELOCITY, share_energy=True)
+    tok = K.fused_token()
+    sm, nm = K.deposit_fft_zy(dpos, dvel, drho, N, L, x0, nx, device.MOMENTUM, reuse_sort=tok, share_energy=True)
+    check(sm, nm, "momentum")
+    tok = K.fused_token()
+    K.timing(True)
+    se, ne = K.deposit_fft_zy(dpos, dvel, drho, N, L, x0, nx, device.ENERGY, reuse_sort=tok, share_energy=True)
+    launches = K.timing_list("fft_z")
+    K.timing(False)
+    assert len(launches) == 0                                       # no deposit + z launch: only the y pass ran
+    check(se, ne, "energy")
+    scale = float(own.abs().pow(2).mean().sqrt())
+    assert float((se[0] - own[0]).abs().max()) / scale < 2e-5 and float((ne[0] - own_n[0]).abs().max()) / scale < 2e-5
+    # energy asked for after something else than the sharing momentum call: the launch of its own, same numbers
+    K.deposit_fft_zy(dpos, dvel, drho, N, L, x0, nx, device.VELOCITY, share_energy=True)
+    tok = K.fused_token()
+    K.timing(True)
+    se2, ne2 = K.deposit_fft_zy(dpos, dvel, drho, N, L, x0, nx, device.ENERGY, reuse_sort=tok, share_energy=True)
+    assert len(K.timing_list("fft_z")) == 1
+    K.timing(False)
+    assert float((se2[0] - own[0]).abs().max()) / scale < 2e-5
+    # the C ABI refuses the flag where it cannot be honoured
+    with pytest.raises(Exception):
+        K.deposit_fft_zy(dpos, dvel, drho, N, L, x0, nx, device.VELOCITY, flags=device.FLAG_SHARE_ENERGY)
+    _free(K)
+
+
 # ---------------------------------------------------------------- C3: exact NN + momentum ----
 def test_config3_nn_slab_against_oracle(K):
     """The C3 lattice (1024 points per axis, interp.py:1063) on a slab of 4 x-rows, 3e6 particles,

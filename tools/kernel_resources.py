@@ -5,7 +5,9 @@ txt = open(sys.argv[1]).read()
 pats = sys.argv[2:]
 blocks = re.split(r"remark: Function Name: ", txt)[1:]
 names = [b.split()[0].strip() for b in blocks]
-dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.strip().split("\n")
+if not names:     # (c++filt without arguments would wait for its standard input)
+    sys.exit("no 'Function Name' remarks in %s" % sys.argv[1])
+dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout.strip().split("\n")
 seen = set()
 for b, dn in zip(blocks, dem):
     dn = dn.replace("(anonymous namespace)::", "").replace("void ", "")
