@@ -1117,6 +1117,9 @@ constexpr int pencil_lanes() {
 #ifndef VPS_PLAIN_MODE
 #define VPS_PLAIN_MODE 2   // (vector launches with plain 16-byte stores: 27.0 ms on one box, 30.7 on two others, against 26.5 - 27.6 with
 #endif                     //  streaming stores everywhere; PMC 113.9 against 117.2 GB written for 103.2 GB of output: not worth the risk)
+#ifndef VPS_SHARED_E_PLAIN
+#define VPS_SHARED_E_PLAIN 1
+#endif
 #ifndef VPS_ST16_ALL
 #define VPS_ST16_ALL 0    // 1: 16-byte stores for 16-line pencils too (experiment)
 #endif
@@ -1432,9 +1435,14 @@ __global__ void __launch_bounds__(TP* pencil_lanes<NC>(), pencil_min_waves<NC>()
     constexpr int WHO = ENERGY ? 2 : 1;
     constexpr bool ST16 = (VPS_ST16_MODE & WHO) && TP >= 8 && TP <= 16 && (VPS_ST16_ALL || TP == 8) && (NC & 1) == 0 && ((NC / 2) * (TP / 2)) % NT == 0;
     constexpr bool PLAIN = (VPS_PLAIN_MODE & WHO) && TP < 16;
-    if constexpr (ST16)
-      r2c_store_tile16<NC, TP, NT, PLAIN>(buf, tidc, p.tw_r2c, out, N, nyq, ZB && c + 1 < nround, NW > 0 ? wr2c : nullptr);
-    else
+    if constexpr (ST16) {
+      // (the energy field of a with_energy launch is the workgroup's LAST component, like the one field of an energy launch:
+      //  plain stores there too, so that the half lines of partner pencils meet in L2 -- VPS_SHARED_E_PLAIN)
+      if (VPS_SHARED_E_PLAIN && !ENERGY && !PLAIN && rho_round)
+        r2c_store_tile16<NC, TP, NT, true>(buf, tidc, p.tw_r2c, out, N, nyq, false, nullptr);
+      else
+        r2c_store_tile16<NC, TP, NT, PLAIN>(buf, tidc, p.tw_r2c, out, N, nyq, ZB && c + 1 < nround, NW > 0 ? wr2c : nullptr);
+    } else
       r2c_store_tile<NC, TP, NT, false, PLAIN>(buf, tidc, p.tw_r2c, out, N, nyq, TP);
   }
   if constexpr (!PERSIST) break;
