@@ -328,11 +328,9 @@ class Workload:
             # momentum and, later in the step, kinetic energy: the momentum launch leaves the energy field's z image behind as
             # well (its rounds accumulate the cell totals of rho v_c that field is made of; device.Kernels.deposit_fft_zy)
             # (a fourth z image: 4 N^3 bytes more -- 29 N^3 in all at C4 -- taken only where that leaves a tenth of the device free)
-            import torch
             share = ("momentum" in self.quantities and "energy" in self.quantities
                      and self.quantities.index("momentum") < self.quantities.index("energy")
-                     and os.environ.get("VPS_SHARE_ENERGY") != "0"
-                     and 30.5 * float(N) ** 2 * nx < 0.88 * torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory)
+                     and os.environ.get("VPS_SHARE_ENERGY") != "0" and K.share_energy_fits(N, nx))
             for i, q in enumerate(self.quantities):
                 qi, nc = dev.QUANTITY[q], NCOMP[q]
                 with K.binning_only():

@@ -334,6 +334,12 @@ class HipKernels:
                                               self._ptr(spec), self._ptr(nyq), self._ptr(work)))
         return spec, nyq
 
+    def share_energy_fits(self, N, nx):
+        """True where the fourth z image of share_energy (4 N^2 nx bytes more: 29 N^2 nx bytes in all for a step with
+        three-component quantities) still leaves a tenth of the device free."""
+        total = torch.cuda.get_device_properties(self.device).total_memory
+        return 30.5 * float(N) ** 2 * nx < 0.88 * total
+
     @staticmethod
     def _component_mask(quantity, component):
         """component: 0..2 or a collection of them -> the bit mask of VPS_FLAG_COMPONENTS."""

@@ -407,8 +407,11 @@ class BoxField:
             flags = _dev.FLAG_REFERENCE_MOMENTUM_BUG if (quantity == "momentum" and REFERENCE_COMPAT["momentum_bug"]) else 0
             pipe.prepare()
             with k.binning_only():      # the spectra go straight into the binning pass
+                # (share_energy: spctrm('momentum') leaves the energy field's z image behind; spctrm('energy') right after it
+                #  then launches no deposit of its own -- vpower/device.py)
                 spec, nyq = k.deposit_fft_zy(src[0], src[1], src[2], self.Nsize, self.Lbox, 0, self.Nsize,
-                                             _dev.QUANTITY[quantity], flags, reuse_sort=getattr(self, "_sort_token", None))
+                                             _dev.QUANTITY[quantity], flags, reuse_sort=getattr(self, "_sort_token", None),
+                                             share_energy=k.share_energy_fits(self.Nsize, self.Nsize))
             self._sort_token = k.fused_token()       # a second quantity of this field skips the particle sort
             tab = pipe.finish(*pipe.accumulate_spectra(spec, nyq))
             tab[:, 1] *= 4 * np.pi * tab[:, 0] ** 2

@@ -526,6 +526,28 @@ def test_fused_energy_matches_unfused(K, N, nx, x0):
     assert float((nyq[0] - n_ref).abs().max()) / scale < 2e-5
 
 
+def test_boxfield_energy_after_momentum_shares_the_deposit(K):
+    """box.spctrm('momentum') then box.spctrm('energy') of a particle-backed field: the second call runs no deposit launch (the
+    momentum launch left the energy field's z image behind, VPS_FLAG_SHARE_ENERGY) -- and both tables match the oracle."""
+    from vpower import interp
+    N, L, Np = 128, 1.0, 300000
+    pos, vel, mass, dens = synth(77, Np, L)
+    gp = interp.GasParticles(pos, mass, dens, vel, L)
+    box = gp.deposit_to_field(N)
+    got_m = box.spctrm("momentum")
+    K.timing(True)
+    got_e = box.spctrm("energy")
+    z_launches = len(K.timing_list("fft_z"))
+    K.timing(False)
+    assert z_launches == 0
+    vec = orc.density_velocity_vector(vel.astype(np.float64), dens.astype(np.float64))
+    v, m = orc.vm_from_vec_grid(orc.deposit_to_grid_fast(vec, pos, N, L), L / N, zero_empty=True)
+    for got, q in ((got_m, "momentum"), (got_e, "energy")):
+        ref = orc.box_spctrm(v[..., 0], v[..., 1], v[..., 2], m, L / N, q)
+        assert np.array_equal(got.Nsample, ref[:, 3])
+        assert np.allclose(got.Psum, ref[:, 2], rtol=PSUM_RTOL, atol=0)
+
+
 def test_particle_backed_boxfield_takes_the_fused_path_and_matches_the_grid_path():
     """gp.deposit_to_field(N).spctrm(q) goes from the particles to P(k) without a grid; touching a grid
     attribute afterwards materialises the field, and the classic grid path gives the same spectrum."""
